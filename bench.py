@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the FIR hot path on MI355X, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2]
+
+Default workload = BASELINE.json configs[1]: stream_filter's 127-tap real-tap
+lowpass on 2^28 complex-float samples, resident in HBM, one MI355X.  A "step" is
+one pass of the FIR over that 2^28-sample buffer (the stream continues from step
+to step: the filter history carries).  With N > 1 (launched by torch.distributed.run,
+one rank per GPU) the stream is N * 2^28 samples cut into contiguous chunks, one per
+GPU, each primed with its left halo (ntaps-1 samples regenerated from the
+counter-based input), no data-path collective: weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = samples all ranks filtered / max-over-ranks
+time, inputs already in HBM.  `roofline` prices the dominant kernel against HBM
+(algorithmic bytes: 16 B per complex sample = 8 read + 8 written).
+`cpu_baseline` times the reference's own kfr::fir (oracle/_ref/ref_harness, built
+from /root/reference in the build container) on a bounded sample on one host core.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (description, complex?, taps builder, log2 samples per GPU, channels)
+    "c2": ("stream_filter 127-tap complex-float lowpass on 2^28 samples, in-memory (BASELINE configs[1])",
+           True, lambda S: S.fir_lowpass(127, 0.1), 28, 1),
+    "c1": ("hilbert default taps (127) on 2^24 real float32 samples, in-memory (BASELINE configs[0] kernel-only)",
+           False, lambda S: S.hilbert(127), 24, 1),
+    "c1big": ("hilbert 127 taps on 2^28 real float32 samples, in-memory", False, lambda S: S.hilbert(127), 28, 1),
+    "c2real": ("127-tap lowpass on 2^28 real float32 samples, in-memory", False, lambda S: S.fir_lowpass(127, 0.1), 28, 1),
+    "hilbc": ("hilbert 127 taps on 2^28 complex samples, in-memory", True, lambda S: S.hilbert(127), 28, 1),
+    "c3": ("stream_filter 4095-tap bandpass on 2^26 complex samples (direct form), in-memory (BASELINE configs[2])",
+           True, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 26, 1),
+    "c4": ("64 channels x 2^22 real samples, hilbert 127 taps (BASELINE configs[3] first stage)",
+           False, lambda S: S.hilbert(127), 22, 64),
+    "lp255": ("255-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(255, 0.1), 28, 1),
+}
+
+
+def fill_counter_based(x, first_sample, seed=0x5D12):
+    """Uniform [-1,1) input defined by a counter-based generator: the value of
+    float k of sample s depends only on (seed, s, k), so any rank can regenerate
+    any part of the global stream (its chunk and the halo before it)."""
+    import torch
+    n = x.shape[0]
+    w = x.shape[1]
+    step = 1 << 24
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        idx = torch.arange(first_sample + lo, first_sample + hi, device=x.device, dtype=torch.int64)
+        for k in range(w):
+            v = (idx * w + k + seed * 0x9E3779B9) & 0xFFFFFFFF
+            v = (v ^ (v >> 16)) * 0x45D9F3B & 0xFFFFFFFF
+            v = (v ^ (v >> 16)) * 0x45D9F3B & 0xFFFFFFFF
+            v = v ^ (v >> 16)
+            x[lo:hi, k] = (v >> 8).to(torch.float32) * (2.0 / (1 << 24)) - 1.0
+
+
+def cpu_baseline(taps, cplx, log2n):
+    """Time the reference's kfr::fir (oracle/_ref/ref_harness) on one core over a
+    bounded sample of the same workload; falls back to the C port of the oracle."""
+    n = 1 << log2n
+    rng = np.random.default_rng(0x5D12)
+    x = rng.uniform(-1, 1, n * (2 if cplx else 1)).astype(np.float32)
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    what = "first 2^%d %s samples of the workload's stream shape, %d taps, 1 process" % (
+        log2n, "complex" if cplx else "real", len(taps))
+    if os.path.exists(harness):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            tp, xp = os.path.join(d, "taps.bin"), os.path.join(d, "x.bin")
+            np.asarray(taps, np.float32).tofile(tp)
+            x.tofile(xp)
+            with open(xp, "rb") as fin, open(os.devnull, "wb") as fout:
+                t0 = time.perf_counter()
+                subprocess.run([harness, "fir", "complex" if cplx else "real", tp, "65536"],
+                               stdin=fin, stdout=fout, check=True)
+                dt = time.perf_counter() - t0
+        return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+                "sample": what + " (reference kfr::fir via oracle/_ref/ref_harness, g++ -O3 -ffast-math -DNDEBUG)"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    f = O.Fir(taps, cplx, acc64=False)
+    xs = x.view(np.complex64) if cplx else x
+    t0 = time.perf_counter()
+    f.process(xs)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": what + " (oracle/sdr_oracle.c fp32 port; oracle/_ref not present)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=27)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sdr_amd as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libsdr_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    desc, cplx, mk_taps, log2n, channels = WORKLOADS[args.workload]
+    taps = mk_taps(S)
+    n = 1 << log2n
+    w = 2 if cplx else 1
+    st = S.FirState(taps, cplx, channels=channels, device=local_rank)
+
+    x = torch.empty((channels * n, w), dtype=torch.float32, device=dev)
+    first = rank * n * channels
+    fill_counter_based(x, first)
+    y = torch.empty_like(x)
+    if rank > 0 and channels == 1:
+        # prime the history with the left halo of this rank's chunk
+        halo = torch.empty((len(taps) - 1, w), dtype=torch.float32, device=dev)
+        fill_counter_based(halo, first - (len(taps) - 1))
+        st.process_tensor(halo.view(-1) if not cplx else halo)
+    xin = x if cplx else x.view(channels, n) if channels > 1 else x.view(-1)
+    yout = y if cplx else y.view(channels, n) if channels > 1 else y.view(-1)
+    if cplx and channels > 1:
+        xin, yout = x.view(channels, n, 2), y.view(channels, n, 2)
+
+    for _ in range(args.warmup):
+        st.process_tensor(xin, yout)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        st.process_tensor(xin, yout)  # launches on torch's current stream
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # per-launch device time of the FIR kernel (+ its 2 us history-carry kernel),
+    # HIP events on the launch stream
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kern_ms_avg = float(np.mean(kern_ms))
+
+    if rank == 0:
+        samples_per_step = n * channels * world
+        value = samples_per_step * args.steps / elapsed / 1e6
+        bytes_per_sample = 8 * w  # 4*w read + 4*w written
+        achieved = n * channels * bytes_per_sample / (kern_ms_avg * 1e-3) / 1e9
+        flops = 2.0 * w * len(taps) * n * channels  # dense nominal
+        out = {
+            "metric": "Msamples/s (FIR hot path: %s)" % args.workload,
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "samples_per_gpu": n * channels, "channels": channels,
+                       "taps": int(len(taps)), "sample_kind": "complex64" if cplx else "float32",
+                       "kernel": st.kernel_name, "sharding": "contiguous chunks with regenerated halo, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kern_ms_avg, "kernel_ms_min": float(np.min(kern_ms)),
+                         "algorithmic_bytes_per_launch": n * channels * bytes_per_sample,
+                         "valu_tflops_dense_nominal": flops / (kern_ms_avg * 1e-3) / 1e12,
+                         "valu_frac_of_157.3": flops / (kern_ms_avg * 1e-3) / 157.3e12},
+        }
+        tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tj):
+            with open(tj) as f:
+                out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(taps, cplx, min(args.cpu_log2n, log2n))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+/* sdr_amd.h -- C ABI of libsdr_amd.so: the MI355X (gfx950) implementation of
+ * fbbdev/sdr's sample-stream FIR hot path.
+ *
+ * The reference has no FFI on this path: kfr::fir is a header-only template
+ * inlined into each block's main().  These entry points are what a binding for
+ * the path would bind; each cites the reference interface it replaces.  Plain C
+ * types only, integer status returns (0 = success, negative = error; text via
+ * sdr_last_error()), no exceptions cross the boundary.  One caller thread per
+ * handle.
+ *
+ * Sample layout (include/sdr/signal.hpp:36-37 of the reference): real samples
+ * are float32, complex samples are interleaved {float re, float im}.  Taps are
+ * real float32 (kfr::fir_state<float, U>).
+ */
+#ifndef SDR_AMD_H
+#define SDR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SDR_OK = 0,
+    SDR_ERR_INVALID = -1,   /* bad argument */
+    SDR_ERR_NO_DEVICE = -2, /* no usable HIP device: there is NO CPU fallback */
+    SDR_ERR_HIP = -3,       /* a HIP runtime call failed */
+    SDR_ERR_NOMEM = -4
+};
+
+enum { SDR_REAL = 0, SDR_COMPLEX = 1 };
+enum { SDR_LOWPASS = 0, SDR_HIGHPASS = 1, SDR_BANDPASS = 2, SDR_BANDSTOP = 3 };
+
+typedef struct sdr_fir sdr_fir_t;
+
+/* Library / device ------------------------------------------------------- */
+const char* sdr_version(void);
+/* Text of the last error on the calling thread ("" if none). */
+const char* sdr_last_error(void);
+/* Number of HIP devices visible (0 when none; never fails). */
+int sdr_device_count(void);
+
+/* Tap design (host code) -------------------------------------------------- */
+/* Replaces sdr::hilbert<float>(n)  (reference include/sdr/hilbert.hpp:33-81,
+ * called at blocks/hilbert.cpp:45 and blocks/gen.cpp:138).  n >= 5: for
+ * n <= 4 the reference's design degenerates to 0/0 (all-NaN taps). */
+int sdr_hilbert_taps(float* taps, size_t n);
+/* Replaces kfr::fir_lowpass/highpass/bandpass/bandstop with
+ * kfr::window_blackman (alpha 0.16, symmetric) and normalize=true
+ * (reference libs/kfr/dsp/fir_design.hpp:35-116, window.hpp:290-311).
+ * Frequencies are normalised (Hz / sample_rate); f2 only for band kinds. */
+int sdr_fir_design(int kind, float* taps, size_t n, float f1, float f2);
+
+/* Streaming FIR ----------------------------------------------------------- */
+/* Replaces the kfr::fir_state<T,U> constructor (reference
+ * libs/kfr/dsp/fir.hpp:57-68; blocks/hilbert.cpp:45, blocks/gen.cpp:138):
+ * `ntaps` real taps h[0..ntaps), zeroed history, `channels` independent
+ * streams sharing the taps, samples SDR_REAL or SDR_COMPLEX, on HIP device
+ * `device`.  The tap vector is analysed once: all-zero odd (or even) taps --
+ * the Hilbert structure -- select a kernel that skips them. */
+int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                   size_t channels, int device);
+
+/* Replaces `out = kfr::fir(state, in)` (reference libs/kfr/dsp/fir.hpp:167-171,
+ * 119-148; call sites blocks/hilbert.cpp:72-73, blocks/gen.cpp:235) for buffers
+ * ALREADY IN DEVICE MEMORY:  y[c][i] = sum_j h[j] x[c][i-j], i in [0,n), with
+ * x[c][<0] taken from the history carried by the handle (zeros after create /
+ * reset).  Channel c starts at in + c*in_stride samples (out likewise).  Exactly
+ * n outputs per channel; afterwards the history holds the last ntaps-1 inputs,
+ * so results do not depend on how a stream is cut into calls.  Asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = the default stream); in and out must not
+ * overlap.  Allocates nothing. */
+int sdr_fir_process_device(sdr_fir_t* f, const void* d_in, size_t in_stride, size_t n,
+                           void* d_out, size_t out_stride, void* hip_stream);
+
+/* Same contract for HOST buffers (any host memory; pinned memory from
+ * sdr_host_alloc makes the copies asynchronous).  Channels are contiguous:
+ * channel c at in + c*n samples.  Copies H2D, filters, copies D2H on the
+ * handle's own stream and returns when `out` is complete. */
+int sdr_fir_process(sdr_fir_t* f, const void* in, size_t n, void* out);
+
+/* Pipelined form of sdr_fir_process for callers that overlap pipe I/O with
+ * the GPU (the blocks' main loops): submit queues H2D + filter + D2H for
+ * staging slot `slot` (0 or 1) and returns at once; wait blocks until that
+ * slot's `out` is complete.  Buffers must stay valid and (for overlap) be
+ * pinned until the matching wait.  Submissions execute in order, so the
+ * history chains exactly as with sdr_fir_process. */
+int sdr_fir_submit(sdr_fir_t* f, int slot, const void* in, size_t n, void* out);
+int sdr_fir_wait(sdr_fir_t* f, int slot);
+
+/* Replaces kfr::filter_fir::reset (reference libs/kfr/dsp/fir.hpp:195-199):
+ * zero the history of every channel. */
+int sdr_fir_reset(sdr_fir_t* f);
+void sdr_fir_destroy(sdr_fir_t* f);
+
+/* Introspection (for tests / benchmarks). */
+size_t sdr_fir_ntaps(const sdr_fir_t* f);
+/* 1 = dense kernel, 2 = every-other-tap (Hilbert) kernel. */
+int sdr_fir_tap_stride(const sdr_fir_t* f);
+/* Name of the HIP kernel a process call launches (for profiles). */
+const char* sdr_fir_kernel_name(const sdr_fir_t* f);
+
+/* Pinned host memory (replaces the reference's SampleAllocator,
+ * include/sdr/signal.hpp:41-69, for buffers that feed the GPU). */
+void* sdr_host_alloc(size_t bytes);
+void sdr_host_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_AMD_H */

@@ -1,0 +1,212 @@
+"""ctypes binding of libsdr_amd.so.  Signatures follow include/sdr_amd.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+SDR_REAL, SDR_COMPLEX = 0, 1
+_KINDS = {"lowpass": 0, "highpass": 1, "bandpass": 2, "bandstop": 3}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class SdrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sdr_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libsdr_amd.so")
+
+
+def lib():
+    """Load libsdr_amd.so (built in-tree by `make -C sdr_amd/csrc`).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError("libsdr_amd.so is not built (%s missing): run `make -C sdr_amd/csrc` "
+                              "or __graft_entry__.build(); there is no fallback path" % path)
+        L = C.CDLL(path)
+        fp, vp, sz = C.POINTER(C.c_float), C.c_void_p, C.c_size_t
+        L.sdr_version.restype = C.c_char_p
+        L.sdr_last_error.restype = C.c_char_p
+        L.sdr_device_count.restype = C.c_int
+        L.sdr_hilbert_taps.argtypes = [fp, sz]
+        L.sdr_fir_design.argtypes = [C.c_int, fp, sz, C.c_float, C.c_float]
+        L.sdr_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int]
+        L.sdr_fir_process_device.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+        L.sdr_fir_process.argtypes = [vp, vp, sz, vp]
+        L.sdr_fir_submit.argtypes = [vp, C.c_int, vp, sz, vp]
+        L.sdr_fir_wait.argtypes = [vp, C.c_int]
+        L.sdr_fir_reset.argtypes = [vp]
+        L.sdr_fir_destroy.argtypes = [vp]
+        L.sdr_fir_destroy.restype = None
+        L.sdr_fir_ntaps.argtypes = [vp]
+        L.sdr_fir_ntaps.restype = sz
+        L.sdr_fir_tap_stride.argtypes = [vp]
+        L.sdr_fir_kernel_name.argtypes = [vp]
+        L.sdr_fir_kernel_name.restype = C.c_char_p
+        L.sdr_host_alloc.argtypes = [sz]
+        L.sdr_host_alloc.restype = vp
+        L.sdr_host_free.argtypes = [vp]
+        L.sdr_host_free.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SdrError(rc, lib().sdr_last_error().decode())
+
+
+def version():
+    return lib().sdr_version().decode()
+
+
+def device_count():
+    return lib().sdr_device_count()
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def hilbert(n):
+    """Hilbert-transformer taps, as sdr::hilbert<float>(n) in the reference."""
+    t = np.empty(int(n), np.float32)
+    _check(lib().sdr_hilbert_taps(_fp(t), int(n)))
+    return t
+
+
+def fir_design(kind, n, f1, f2=0.0):
+    t = np.empty(int(n), np.float32)
+    _check(lib().sdr_fir_design(_KINDS[kind], _fp(t), int(n), f1, f2))
+    return t
+
+
+def fir_lowpass(n, cutoff):
+    return fir_design("lowpass", n, cutoff)
+
+
+def fir_highpass(n, cutoff):
+    return fir_design("highpass", n, cutoff)
+
+
+def fir_bandpass(n, f1, f2):
+    return fir_design("bandpass", n, f1, f2)
+
+
+def fir_bandstop(n, f1, f2):
+    return fir_design("bandstop", n, f1, f2)
+
+
+def host_alloc(nbytes):
+    p = lib().sdr_host_alloc(nbytes)
+    if not p:
+        raise SdrError(-4, lib().sdr_last_error().decode())
+    return p
+
+
+def host_free(p):
+    lib().sdr_host_free(p)
+
+
+class FirState:
+    """Streaming FIR state on one GPU: real taps, real or complex samples,
+    `channels` independent streams.  History is zero after construction and is
+    carried from call to call, like kfr::fir_state in the reference."""
+
+    def __init__(self, taps, complex_samples=False, channels=1, device=0):
+        taps = np.ascontiguousarray(taps, np.float32)
+        self.complex_samples = bool(complex_samples)
+        self.channels = int(channels)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _check(lib().sdr_fir_create(C.byref(self._h), _fp(taps), len(taps),
+                                    SDR_COMPLEX if self.complex_samples else SDR_REAL,
+                                    self.channels, self.device))
+
+    # -- introspection
+    @property
+    def ntaps(self):
+        return lib().sdr_fir_ntaps(self._h)
+
+    @property
+    def tap_stride(self):
+        return lib().sdr_fir_tap_stride(self._h)
+
+    @property
+    def kernel_name(self):
+        return lib().sdr_fir_kernel_name(self._h).decode()
+
+    @property
+    def dtype(self):
+        return np.complex64 if self.complex_samples else np.float32
+
+    # -- host buffers
+    def process(self, x):
+        """x: (n,) or (channels, n) host array -> same shape, filtered."""
+        x = np.ascontiguousarray(x, self.dtype)
+        n = x.shape[-1]
+        if x.size != n * self.channels:
+            raise ValueError("expected %d channel(s) of samples" % self.channels)
+        y = np.empty_like(x)
+        _check(lib().sdr_fir_process(self._h, x.ctypes.data, n, y.ctypes.data))
+        return y
+
+    def submit(self, slot, in_ptr, n, out_ptr):
+        _check(lib().sdr_fir_submit(self._h, slot, in_ptr, n, out_ptr))
+
+    def wait(self, slot):
+        _check(lib().sdr_fir_wait(self._h, slot))
+
+    # -- device buffers
+    def process_device(self, d_in, n, d_out, in_stride=None, out_stride=None, stream=None):
+        """Raw device pointers (ints).  Asynchronous on `stream` (a hipStream_t value)."""
+        _check(lib().sdr_fir_process_device(self._h, d_in, n if in_stride is None else in_stride, n,
+                                            d_out, n if out_stride is None else out_stride,
+                                            C.c_void_p(stream or 0)))
+
+    def process_tensor(self, x, out=None):
+        """torch tensors resident on this state's GPU (torch is only the
+        allocator here): float32 (n,) / (channels, n) for real samples, complex64 or
+        float32 (..., n, 2) for complex.  Runs on torch's current stream."""
+        import torch
+        assert x.is_cuda and x.is_contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        assert out.is_cuda and out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype
+        if self.complex_samples:
+            n = x.shape[-1] if x.is_complex() else x.shape[-2]
+        else:
+            n = x.shape[-1]
+        per = x.numel() if x.is_complex() or not self.complex_samples else x.numel() // 2
+        if per != n * self.channels:
+            raise ValueError("tensor shape does not match %d channel(s)" % self.channels)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self.process_device(x.data_ptr(), n, out.data_ptr(), stream=stream)
+        return out
+
+    def reset(self):
+        _check(lib().sdr_fir_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdr_fir_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fir(state, x):
+    """kfr::fir(state, x): filter `x` through `state`, advancing its history."""
+    if hasattr(x, "is_cuda"):
+        return state.process_tensor(x)
+    return state.process(x)

@@ -1,0 +1,323 @@
+// sdr_capi.hip -- the C ABI of libsdr_amd.so (include/sdr_amd.h) over the gfx950
+// kernels in fir_kernels.hip.  There is no CPU compute path in this library:
+// without a HIP device every compute entry point returns SDR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sdr_amd.h"
+#include "errors.h"
+#include "fir_kernels.h"
+
+namespace sdr_amd {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+void clear_error() { g_last_error.clear(); }
+
+static int hip_fail(hipError_t e, const char* what) {
+    int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? SDR_ERR_NO_DEVICE
+               : (e == hipErrorOutOfMemory)                          ? SDR_ERR_NOMEM
+                                                                     : SDR_ERR_HIP;
+    return fail(code, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SDR_HIP(expr)                                              \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) return sdr_amd::hip_fail(e_, #expr); \
+    } while (0)
+
+// Makes `device` current for the scope, restores the caller's device after.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+} // namespace sdr_amd
+
+using namespace sdr_amd;
+
+struct sdr_fir {
+    int device = 0;
+    int kind = SDR_REAL;
+    size_t channels = 1;
+    size_t ntaps = 0;
+    int w = 1; // floats per sample
+    const KernelInfo* k = nullptr;
+    int nchunks = 0;
+    int hist_len = 0;
+    int shift = 0;
+    float* d_taps = nullptr;
+    float* d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    hipStream_t stream = nullptr; // used by the host-buffer entry points
+    struct Slot {
+        float* d_in = nullptr;
+        float* d_out = nullptr;
+        size_t cap = 0; // floats
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    } slot[2];
+};
+
+extern "C" const char* sdr_version(void) { return "sdr_amd 0.1 (gfx950)"; }
+extern "C" const char* sdr_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int sdr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                              size_t channels, int device) {
+    clear_error();
+    if (!out) return fail(SDR_ERR_INVALID, "sdr_fir_create: out is NULL");
+    *out = nullptr;
+    if (!taps || ntaps == 0) return fail(SDR_ERR_INVALID, "sdr_fir_create: no taps");
+    if (ntaps > (1u << 20)) return fail(SDR_ERR_INVALID, "sdr_fir_create: too many taps");
+    if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
+        return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
+    if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(SDR_ERR_NO_DEVICE, "sdr_fir_create: no HIP device (libsdr_amd has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SDR_ERR_INVALID, "sdr_fir_create: device out of range");
+
+    // Tap structure: every other tap zero (Hilbert transformer, reference
+    // include/sdr/hilbert.hpp:46-55) => a kernel that skips them.
+    bool odd_zero = ntaps >= 8, even_zero = ntaps >= 8;
+    for (size_t j = 0; j < ntaps; ++j) {
+        if (taps[j] != 0.0f) {
+            if (j & 1) odd_zero = false;
+            else even_zero = false;
+        }
+    }
+    int stride = 1, shift = 0;
+    if (odd_zero && !even_zero) stride = 2, shift = 0;
+    else if (even_zero && !odd_zero) stride = 2, shift = 1;
+    if (env_int("SDR_AMD_DENSE", 0)) stride = 1, shift = 0;
+
+    int R = env_int("SDR_AMD_R", stride == 2 ? 16 : 8);
+    if (R != 4 && R != 8 && R != 16) return fail(SDR_ERR_INVALID, "SDR_AMD_R must be 4, 8 or 16");
+    const KernelInfo* k = find_kernel(R, stride, sample_kind == SDR_REAL);
+    if (!k) return fail(SDR_ERR_INVALID, "sdr_fir_create: no kernel for this configuration");
+
+    // compacted taps g[i] = h[stride*i + shift], zero-padded to whole chunk pairs
+    const size_t kept = (ntaps - shift + stride - 1) / stride;
+    const size_t span = (kept - 1) * stride + 1; // sample offsets covered
+    int nchunks = (int)((span + R - 1) / R);
+    nchunks += nchunks & 1;
+    if (nchunks < 2) nchunks = 2;
+    const size_t per_chunk = R / stride;
+    std::vector<float> g((size_t)nchunks * per_chunk, 0.0f);
+    for (size_t i = 0; i < kept; ++i) g[i] = taps[stride * i + shift];
+
+    sdr_fir* f = new (std::nothrow) sdr_fir();
+    if (!f) return fail(SDR_ERR_NOMEM, "sdr_fir_create: out of memory");
+    f->device = device;
+    f->kind = sample_kind;
+    f->channels = channels;
+    f->ntaps = ntaps;
+    f->w = sample_kind == SDR_COMPLEX ? 2 : 1;
+    f->k = k;
+    f->nchunks = nchunks;
+    f->shift = shift;
+    f->hist_len = nchunks * R + 4;
+
+    DeviceGuard guard(device);
+    int rc = SDR_OK;
+    auto bail = [&](hipError_t err, const char* what) {
+        rc = hip_fail(err, what);
+        std::string keep = g_last_error;
+        sdr_fir_destroy(f);
+        g_last_error = keep;
+        return rc;
+    };
+    if (guard.err != hipSuccess) return bail(guard.err, "hipSetDevice");
+    if ((e = prepare_kernel(*k, nchunks)) != hipSuccess) return bail(e, "tap count too large for the direct-form kernel");
+    const size_t hist_bytes = channels * (size_t)f->hist_len * f->w * sizeof(float);
+    if ((e = hipMalloc(&f->d_taps, g.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(taps)");
+    if ((e = hipMalloc(&f->d_hist[0], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
+    if ((e = hipMalloc(&f->d_hist[1], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
+    if ((e = hipMemcpy(f->d_taps, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(taps)");
+    if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
+    if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
+    if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    for (auto& s : f->slot)
+        if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    *out = f;
+    return SDR_OK;
+}
+
+extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
+    if (!f) return;
+    DeviceGuard guard(f->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    for (auto& s : f->slot) {
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (f->d_taps) (void)hipFree(f->d_taps);
+    if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
+    if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, size_t n, float* d_out,
+                               size_t out_stride, hipStream_t stream) {
+    if (n == 0) return SDR_OK;
+    if (f->channels > 1 && (in_stride < n || out_stride < n))
+        return fail(SDR_ERR_INVALID, "sdr_fir_process_device: channel stride smaller than n");
+    const size_t wbytes = f->w * sizeof(float);
+    if (((uintptr_t)d_in % wbytes) || ((uintptr_t)d_out % wbytes))
+        return fail(SDR_ERR_INVALID, "sdr_fir_process_device: buffers must be aligned to the sample size");
+    FirArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.hist = f->d_hist[f->cur];
+    a.taps = f->d_taps;
+    a.n = (long long)n;
+    a.in_stride = (long long)in_stride;
+    a.out_stride = (long long)out_stride;
+    a.nchunks = f->nchunks;
+    a.hist_len = f->hist_len;
+    a.shift = f->shift;
+    const bool multi = f->channels > 1;
+    a.vec_in = ((uintptr_t)d_in % 16 == 0) && (!multi || (in_stride * f->w) % 4 == 0);
+    a.vec_out = ((uintptr_t)d_out % 16 == 0) && (!multi || (out_stride * f->w) % 4 == 0);
+    SDR_HIP(launch_fir(*f->k, a, f->channels, stream));
+    SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
+                                 f->hist_len, f->w, f->channels, stream));
+    f->cur ^= 1;
+    return SDR_OK;
+}
+
+extern "C" int sdr_fir_process_device(sdr_fir_t* f, const void* d_in, size_t in_stride, size_t n, void* d_out,
+                                      size_t out_stride, void* hip_stream) {
+    clear_error();
+    if (!f) return fail(SDR_ERR_INVALID, "sdr_fir_process_device: NULL handle");
+    if (n && (!d_in || !d_out)) return fail(SDR_ERR_INVALID, "sdr_fir_process_device: NULL buffer");
+    DeviceGuard guard(f->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    return process_device_impl(f, (const float*)d_in, in_stride, n, (float*)d_out, out_stride, (hipStream_t)hip_stream);
+}
+
+static int ensure_slot(sdr_fir* f, sdr_fir::Slot& s, size_t floats) {
+    if (s.cap >= floats) return SDR_OK;
+    // growing a slot: wait for anything that may still use the old buffers
+    SDR_HIP(hipStreamSynchronize(f->stream));
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    s.d_in = s.d_out = nullptr;
+    s.cap = 0;
+    size_t cap = std::max<size_t>(floats, 1 << 16);
+    cap = (cap + 1023) & ~(size_t)1023;
+    SDR_HIP(hipMalloc(&s.d_in, cap * sizeof(float)));
+    SDR_HIP(hipMalloc(&s.d_out, cap * sizeof(float)));
+    s.cap = cap;
+    return SDR_OK;
+}
+
+extern "C" int sdr_fir_submit(sdr_fir_t* f, int slot, const void* in, size_t n, void* out) {
+    clear_error();
+    if (!f) return fail(SDR_ERR_INVALID, "sdr_fir_submit: NULL handle");
+    if (slot < 0 || slot > 1) return fail(SDR_ERR_INVALID, "sdr_fir_submit: slot must be 0 or 1");
+    if (n && (!in || !out)) return fail(SDR_ERR_INVALID, "sdr_fir_submit: NULL buffer");
+    DeviceGuard guard(f->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    sdr_fir::Slot& s = f->slot[slot];
+    if (s.pending) {
+        SDR_HIP(hipEventSynchronize(s.done));
+        s.pending = false;
+    }
+    if (n == 0) return SDR_OK;
+    const size_t floats = n * f->channels * f->w;
+    int rc = ensure_slot(f, s, floats);
+    if (rc != SDR_OK) return rc;
+    SDR_HIP(hipMemcpyAsync(s.d_in, in, floats * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    rc = process_device_impl(f, s.d_in, n, n, s.d_out, n, f->stream);
+    if (rc != SDR_OK) return rc;
+    SDR_HIP(hipMemcpyAsync(out, s.d_out, floats * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    SDR_HIP(hipEventRecord(s.done, f->stream));
+    s.pending = true;
+    return SDR_OK;
+}
+
+extern "C" int sdr_fir_wait(sdr_fir_t* f, int slot) {
+    clear_error();
+    if (!f) return fail(SDR_ERR_INVALID, "sdr_fir_wait: NULL handle");
+    if (slot < 0 || slot > 1) return fail(SDR_ERR_INVALID, "sdr_fir_wait: slot must be 0 or 1");
+    sdr_fir::Slot& s = f->slot[slot];
+    if (!s.pending) return SDR_OK;
+    DeviceGuard guard(f->device);
+    SDR_HIP(hipEventSynchronize(s.done));
+    s.pending = false;
+    return SDR_OK;
+}
+
+extern "C" int sdr_fir_process(sdr_fir_t* f, const void* in, size_t n, void* out) {
+    int rc = sdr_fir_submit(f, 0, in, n, out);
+    if (rc != SDR_OK) return rc;
+    return sdr_fir_wait(f, 0);
+}
+
+extern "C" int sdr_fir_reset(sdr_fir_t* f) {
+    clear_error();
+    if (!f) return fail(SDR_ERR_INVALID, "sdr_fir_reset: NULL handle");
+    DeviceGuard guard(f->device);
+    SDR_HIP(hipStreamSynchronize(f->stream));
+    SDR_HIP(hipDeviceSynchronize());
+    const size_t hist_bytes = f->channels * (size_t)f->hist_len * f->w * sizeof(float);
+    SDR_HIP(hipMemset(f->d_hist[0], 0, hist_bytes));
+    SDR_HIP(hipMemset(f->d_hist[1], 0, hist_bytes));
+    return SDR_OK;
+}
+
+extern "C" size_t sdr_fir_ntaps(const sdr_fir_t* f) { return f ? f->ntaps : 0; }
+extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? f->k->stride : 0; }
+extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) { return f ? f->k->name : ""; }
+
+extern "C" void* sdr_host_alloc(size_t bytes) {
+    clear_error();
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        hip_fail(e, "hipHostMalloc");
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void sdr_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
