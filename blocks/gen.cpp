@@ -1,0 +1,119 @@
+// gen -- drop-in for the reference waveform source (blocks/gen.cpp:83-268), sample
+// synthesis on the GPU (libsdr_amd's generator restates the reference's fp32 recipe:
+// polynomial sine, per-block phase recurrence).
+//
+//   gen [help] [freq=]FREQ [[unit=](hertz|hz|meters|meter|m|samples|stream)]
+//       [[waveform=](cosine|sine|square|triangle|sawtooth)] sample_rate=HERTZ [amp=AMPLITUDE]
+//       [phi=PHASE] [mode=(real|complex)] [hilbert_taps=COUNT] [stream=ID]
+//
+// Runs until its output closes (SIGPIPE), like the reference.
+// Not implemented yet (reported as an error): unit=stream (frequency control input,
+// blocks/gen.cpp:61-81) and complex square/triangle/sawtooth (the reference's second
+// FIR call site, blocks/gen.cpp:231-260).
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <vector>
+
+#include "../include/sdr_amd.h"
+#include "host/cli.hpp"
+#include "host/wire.hpp"
+
+namespace {
+const cli::Choices kUnits = {{"hertz", 0}, {"hz", 0}, {"meters", 1}, {"meter", 1}, {"m", 1}, {"samples", 2}, {"stream", 3}};
+const cli::Choices kWaveforms = {{"cosine", SDR_WAVE_COSINE}, {"sine", SDR_WAVE_SINE}, {"square", SDR_WAVE_SQUARE},
+                                 {"triangle", SDR_WAVE_TRIANGLE}, {"sawtooth", SDR_WAVE_SAWTOOTH}};
+const cli::Choices kModes = {{"real", SDR_REAL}, {"complex", SDR_COMPLEX}};
+
+// include/sdr/options.hpp:120-141 of the reference, fp32
+float cycles_per_sample(int unit, float f, uint64_t sample_rate) {
+    switch (unit) {
+        case 1: f = 299792458.0f / f; /* fallthrough */
+        case 0: f /= static_cast<float>(sample_rate); break;
+        case 2: f = 1.0f / f; break;
+        default: break;
+    }
+    if (unit == 3 || std::isnan(f) || std::isinf(f)) return 0.0f;
+    return f;
+}
+} // namespace
+
+int main(int argc, char* argv[]) {
+    cli::Option freq = cli::Option::real("freq", "FREQ", 0.0f, true);
+    cli::Option unit = cli::Option::choice("unit", kUnits, 0);
+    cli::Option waveform = cli::Option::choice("waveform", kWaveforms, SDR_WAVE_COSINE);
+    cli::Option sample_rate = cli::Option::uint("sample_rate", "HERTZ", 0, true);
+    cli::Option amp = cli::Option::real("amp", "AMPLITUDE", 1.0f);
+    cli::Option phase = cli::Option::real("phi", "PHASE", 0.0f);
+    cli::Option mode = cli::Option::choice("mode", kModes, SDR_COMPLEX);
+    cli::Option hilbert_taps = cli::Option::uint("hilbert_taps", "COUNT", 127);
+    cli::Option id = cli::Option::uint("stream", "ID", 0);
+    const std::vector<cli::Option*> pos = {&freq, &unit, &waveform};
+    const std::vector<cli::Option*> kw = {&sample_rate, &amp, &phase, &mode, &hilbert_taps, &id};
+    if (!cli::parse(pos, kw, argc, argv, std::cerr)) return -1;
+
+    if (!freq.is_set() || !sample_rate.is_set()) {
+        std::cerr << "error: gen: options 'freq' and 'sample_rate' are required" << std::endl;
+        cli::usage(argv[0], pos, kw, std::cerr);
+        return -1;
+    }
+    if (unit.as_choice() == 3) {
+        const float f = freq.as_float();
+        if (!(f >= 0 && f <= 65535 && f == std::floor(f))) {
+            std::cerr << "error: gen: " << f << " is not a valid stream id" << std::endl;
+            return -1;
+        }
+        std::cerr << "error: gen: unit=stream (frequency control input) is not implemented in this build" << std::endl;
+        return -1;
+    }
+    if (!cli::valid_stream_id(id.as_uint())) {
+        std::cerr << "error: gen: " << id.as_uint() << " is not a valid stream id" << std::endl;
+        return -1;
+    }
+    const int kind = mode.as_choice();
+    if (kind == SDR_COMPLEX && waveform.as_choice() > SDR_WAVE_SINE) {
+        std::cerr << "error: gen: complex square/triangle/sawtooth are not implemented in this build" << std::endl;
+        return -1;
+    }
+    if (sdr_device_count() < 1) {
+        std::cerr << "error: gen: no HIP device found (this block has no CPU path)" << std::endl;
+        return -1;
+    }
+
+    const size_t elt = kind == SDR_REAL ? 4 : 8;
+    const uint64_t rate = sample_rate.as_uint();
+    const size_t block = sdr_optimal_block_size(elt, rate);                   // gen.cpp:117-118
+    const float cps = cycles_per_sample(unit.as_choice(), freq.as_float(), rate); // :122
+
+    host::PacketHeader hdr;                                                   // :128-132
+    hdr.id = static_cast<uint16_t>(id.as_uint());
+    hdr.content = kind == SDR_REAL ? host::kSignal : host::kComplexSignal;
+    hdr.size = static_cast<uint32_t>(block * elt);
+    hdr.duration = rate ? block * 1000000000ull / rate : 0;
+
+    sdr_gen_t* g = nullptr;
+    const int device = std::getenv("SDR_AMD_DEVICE") ? std::atoi(std::getenv("SDR_AMD_DEVICE")) : 0;
+    if (sdr_gen_create(&g, waveform.as_choice(), kind, amp.as_float(), cps, phase.as_float(), block, device) != SDR_OK) {
+        std::cerr << "error: gen: " << sdr_last_error() << std::endl;
+        return -1;
+    }
+    const size_t blocks_per_call = 512; // ~4 MiB per round trip
+    uint8_t* buf = static_cast<uint8_t*>(sdr_host_alloc(blocks_per_call * block * elt));
+    if (!buf) {
+        std::cerr << "error: gen: " << sdr_last_error() << std::endl;
+        return -1;
+    }
+    for (;;) {
+        if (sdr_gen_generate(g, blocks_per_call, buf) != SDR_OK) {
+            std::cerr << "error: gen: " << sdr_last_error() << std::endl;
+            return -1;
+        }
+        for (size_t b = 0; b < blocks_per_call; ++b) {
+            if (!host::write_full(1, &hdr, sizeof hdr) || !host::write_full(1, buf + b * block * elt, block * elt)) {
+                sdr_gen_destroy(g);
+                sdr_host_free(buf);
+                return 0; // output closed
+            }
+        }
+    }
+}

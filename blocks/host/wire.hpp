@@ -1,0 +1,78 @@
+// wire.hpp -- packet framing and blocking packet I/O for the drop-in blocks.
+//
+// Wire format (must stay byte-compatible with the reference, which writes the
+// raw struct of include/sdr/packet.hpp:28-45): a 16-byte little-endian header
+//   off 0  u16 id        stream id
+//   off 2  u16 content   0 Binary 1 String 2 Time 3 Frequency 4 Wavelength
+//                        5 SampleCount 6 Signal 7 ComplexSignal 8 Spectrum 9 ComplexSpectrum
+//   off 4  u32 size      payload bytes
+//   off 8  u64 duration  nanoseconds, 0 = unknown
+// followed by `size` payload bytes; no padding, magic or trailer.
+// Signal = float32 samples, ComplexSignal = {float re, float im} pairs.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace host {
+
+enum Content : uint16_t {
+    kBinary = 0, kString, kTime, kFrequency, kWavelength, kSampleCount,
+    kSignal, kComplexSignal, kSpectrum, kComplexSpectrum, kContentCount
+};
+
+struct PacketHeader {
+    uint16_t id;
+    uint16_t content;
+    uint32_t size;
+    uint64_t duration;
+};
+static_assert(sizeof(PacketHeader) == 16, "wire header is 16 bytes");
+
+// Reads until `size` bytes arrived, EOF or error; returns bytes read.
+size_t read_full(int fd, void* dst, size_t size);
+// Writes everything or returns false on error.
+bool write_full(int fd, const void* src, size_t size);
+// True when a read on fd would not block right now (data or EOF pending).
+bool input_ready(int fd);
+
+// Sequential packet reader over a byte stream (semantics of the reference's
+// Source::next/recv/drop, lib/sdr/stream.cpp:121-249: unread payload of the
+// previous packet is discarded by next(); a short header is a clean EOF; a short
+// payload yields what arrived and ends the stream).
+class PacketReader {
+public:
+    explicit PacketReader(int fd = 0) : fd_(fd) {}
+    // Advance to the next packet header.  False at end of stream.
+    bool next();
+    const PacketHeader& header() const { return hdr_; }
+    // Read up to `bytes` of the remaining payload into dst; returns bytes read.
+    size_t read_payload(void* dst, size_t bytes);
+    size_t remaining() const { return hdr_.size - consumed_; }
+    bool eof() const { return eof_; }
+    int fd() const { return fd_; }
+
+private:
+    void skip_rest();
+    int fd_;
+    PacketHeader hdr_{};
+    size_t consumed_ = 0;
+    bool eof_ = false;
+};
+
+class PacketWriter {
+public:
+    explicit PacketWriter(int fd = 1) : fd_(fd) {}
+    // Header + payload (hdr.size bytes).  Write errors are ignored like the
+    // reference's Sink::send (lib/sdr/stream.cpp:367-375); a closed pipe ends the
+    // process by SIGPIPE.
+    void send(const PacketHeader& hdr, const void* payload);
+    void flush_to_disk(); // fdatasync when the sink is a regular file
+    int fd() const { return fd_; }
+
+private:
+    int fd_;
+};
+
+} // namespace host

@@ -102,6 +102,33 @@ int sdr_fir_tap_stride(const sdr_fir_t* f);
 /* Name of the HIP kernel a process call launches (for profiles). */
 const char* sdr_fir_kernel_name(const sdr_fir_t* f);
 
+/* Waveform generator ("gen" block producer, fused chains) ------------------ */
+enum { SDR_WAVE_COSINE = 0, SDR_WAVE_SINE = 1, SDR_WAVE_SQUARE = 2, SDR_WAVE_TRIANGLE = 3, SDR_WAVE_SAWTOOTH = 4 };
+typedef struct sdr_gen sdr_gen_t;
+
+/* Replaces sdr::optimal_block_size (reference include/sdr/signal.hpp:73-89):
+ * samples per packet for an element size and sample rate (4 KiB pages). */
+size_t sdr_optimal_block_size(uint64_t element_size, uint64_t sample_rate);
+
+/* Replaces the set-up of the reference generator loop (blocks/gen.cpp:117-132):
+ * amplitude A, frequency in cycles per sample (convert_freq,
+ * include/sdr/options.hpp:120-141), initial phase in degrees, packets of
+ * `block_size` samples.  SDR_REAL supports all five waveforms, SDR_COMPLEX
+ * cosine and sine (A*cexp(j2pi(..)), blocks/gen.cpp:219-230). */
+int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, float amplitude, float cycles_per_sample,
+                   float phase_degrees, size_t block_size, int device);
+/* New frequency from the next block on (the unit=stream control input,
+ * blocks/gen.cpp:167-176). */
+int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample);
+/* Replaces the body of the generator loop (blocks/gen.cpp:183-195, 224-229):
+ * the next `blocks` packets' worth of samples, bit-for-bit the reference's fp32
+ * recipe (polynomial sine, per-block phase recurrence), written to DEVICE
+ * memory d_out, asynchronously on hip_stream. */
+int sdr_gen_generate_device(sdr_gen_t* g, size_t blocks, void* d_out, void* hip_stream);
+/* Same into HOST memory; returns when `out` is complete. */
+int sdr_gen_generate(sdr_gen_t* g, size_t blocks, void* out);
+void sdr_gen_destroy(sdr_gen_t* g);
+
 /* Pinned host memory (replaces the reference's SampleAllocator,
  * include/sdr/signal.hpp:41-69, for buffers that feed the GPU). */
 void* sdr_host_alloc(size_t bytes);

@@ -1,0 +1,20 @@
+// gen_kernels.h -- internal: device waveform generator launch interface.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sdr_amd {
+
+struct GenArgs {
+    float* out;        // blocks*block_size samples (complex: float pairs)
+    const float* phi;  // per-block start phase, cycles in [0,1)
+    long long blocks;
+    long long block_size;
+    float amp;
+    float cps;         // cycles per sample
+    int waveform;      // 0 cosine 1 sine 2 square 3 triangle 4 sawtooth
+    int complex_samples;
+};
+
+hipError_t launch_gen(const GenArgs& a, hipStream_t stream);
+
+} // namespace sdr_amd

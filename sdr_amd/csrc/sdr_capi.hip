@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -12,6 +13,7 @@
 #include "../../include/sdr_amd.h"
 #include "errors.h"
 #include "fir_kernels.h"
+#include "gen_kernels.h"
 
 namespace sdr_amd {
 
@@ -320,4 +322,163 @@ extern "C" void* sdr_host_alloc(size_t bytes) {
 
 extern "C" void sdr_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+// ---- generator -----------------------------------------------------------------
+
+struct sdr_gen {
+    int device = 0;
+    int waveform = 0;
+    int kind = SDR_REAL;
+    float amp = 1.0f, cps = 0.0f, phi = 0.0f, phi_incr = 0.0f;
+    size_t block_size = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t table_free = nullptr; // the phase table may be overwritten after this
+    float* h_phi = nullptr;          // pinned
+    float* d_phi = nullptr;
+    size_t phi_cap = 0;
+    float* d_out = nullptr; // staging for the host entry point
+    size_t out_cap = 0;
+};
+
+static inline float fractf_host(float x) { return x - floorf(x); }
+
+extern "C" size_t sdr_optimal_block_size(uint64_t element_size, uint64_t sample_rate) {
+    if (element_size == 0) return 0;
+    const uint64_t page = 4096, header = 16;
+    uint64_t size = std::max<uint64_t>(1, (2 * page - header) / element_size);
+    if (sample_rate == 0) return (size_t)size;
+    uint64_t a = header, b = element_size;
+    while (b) { uint64_t t = a % b; a = b; b = t; }
+    const uint64_t step = (header / a * element_size) / element_size; // lcm(header, elt)/elt
+    const uint64_t limit = std::max<uint64_t>((page - header) / element_size, step);
+    while (size > limit && (size * 1000000000ull) % sample_rate > 0) size -= step;
+    return (size_t)size;
+}
+
+extern "C" int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, float amplitude,
+                              float cycles_per_sample, float phase_degrees, size_t block_size, int device) {
+    clear_error();
+    if (!out) return fail(SDR_ERR_INVALID, "sdr_gen_create: out is NULL");
+    *out = nullptr;
+    if (waveform < SDR_WAVE_COSINE || waveform > SDR_WAVE_SAWTOOTH) return fail(SDR_ERR_INVALID, "sdr_gen_create: unknown waveform");
+    if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX) return fail(SDR_ERR_INVALID, "sdr_gen_create: bad sample_kind");
+    if (sample_kind == SDR_COMPLEX && waveform > SDR_WAVE_SINE)
+        return fail(SDR_ERR_INVALID, "sdr_gen_create: complex square/triangle/sawtooth are not implemented");
+    if (block_size == 0 || block_size > (1u << 24)) return fail(SDR_ERR_INVALID, "sdr_gen_create: bad block_size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SDR_ERR_NO_DEVICE, "sdr_gen_create: no HIP device (libsdr_amd has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SDR_ERR_INVALID, "sdr_gen_create: device out of range");
+    sdr_gen* g = new (std::nothrow) sdr_gen();
+    if (!g) return fail(SDR_ERR_NOMEM, "sdr_gen_create: out of memory");
+    g->device = device;
+    g->waveform = waveform;
+    g->kind = sample_kind;
+    g->amp = amplitude;
+    g->cps = cycles_per_sample;
+    g->phi = fractf_host(phase_degrees / 360.0f);                      // gen.cpp:123
+    g->phi_incr = fractf_host(cycles_per_sample * (float)block_size);  // gen.cpp:124
+    g->block_size = block_size;
+    DeviceGuard guard(device);
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&g->table_free, hipEventDisableTiming)) != hipSuccess) {
+        int rc = hip_fail(e, "sdr_gen_create");
+        std::string keep = g_last_error;
+        sdr_gen_destroy(g);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = g;
+    return SDR_OK;
+}
+
+extern "C" int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample) {
+    clear_error();
+    if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_set_frequency: NULL handle");
+    g->cps = cycles_per_sample;
+    g->phi_incr = fractf_host(cycles_per_sample * (float)g->block_size);
+    return SDR_OK;
+}
+
+static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
+    if (blocks == 0) return SDR_OK;
+    if (blocks > g->phi_cap) {
+        SDR_HIP(hipEventSynchronize(g->table_free));
+        if (g->h_phi) (void)hipHostFree(g->h_phi);
+        if (g->d_phi) (void)hipFree(g->d_phi);
+        g->h_phi = g->d_phi = nullptr;
+        g->phi_cap = 0;
+        const size_t cap = std::max<size_t>(blocks, 4096);
+        SDR_HIP(hipHostMalloc(&g->h_phi, cap * sizeof(float), hipHostMallocDefault));
+        SDR_HIP(hipMalloc(&g->d_phi, cap * sizeof(float)));
+        g->phi_cap = cap;
+    } else {
+        SDR_HIP(hipEventSynchronize(g->table_free)); // previous table still in use?
+    }
+    // sequential fp32 phase recurrence, one value per block (gen.cpp:185,192,227)
+    float phi = g->phi;
+    for (size_t b = 0; b < blocks; ++b) {
+        g->h_phi[b] = phi;
+        phi = fractf_host(phi + g->phi_incr);
+    }
+    g->phi = phi;
+    SDR_HIP(hipMemcpyAsync(g->d_phi, g->h_phi, blocks * sizeof(float), hipMemcpyHostToDevice, stream));
+    GenArgs a;
+    a.out = d_out;
+    a.phi = g->d_phi;
+    a.blocks = (long long)blocks;
+    a.block_size = (long long)g->block_size;
+    a.amp = g->amp;
+    a.cps = g->cps;
+    a.waveform = g->waveform;
+    a.complex_samples = g->kind == SDR_COMPLEX;
+    SDR_HIP(launch_gen(a, stream));
+    SDR_HIP(hipEventRecord(g->table_free, stream));
+    return SDR_OK;
+}
+
+extern "C" int sdr_gen_generate_device(sdr_gen_t* g, size_t blocks, void* d_out, void* hip_stream) {
+    clear_error();
+    if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_generate_device: NULL handle");
+    if (blocks && !d_out) return fail(SDR_ERR_INVALID, "sdr_gen_generate_device: NULL buffer");
+    DeviceGuard guard(g->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    return gen_device_impl(g, blocks, (float*)d_out, (hipStream_t)hip_stream);
+}
+
+extern "C" int sdr_gen_generate(sdr_gen_t* g, size_t blocks, void* out) {
+    clear_error();
+    if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_generate: NULL handle");
+    if (blocks == 0) return SDR_OK;
+    if (!out) return fail(SDR_ERR_INVALID, "sdr_gen_generate: NULL buffer");
+    DeviceGuard guard(g->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    const size_t floats = blocks * g->block_size * (g->kind == SDR_COMPLEX ? 2 : 1);
+    if (floats > g->out_cap) {
+        SDR_HIP(hipStreamSynchronize(g->stream));
+        if (g->d_out) (void)hipFree(g->d_out);
+        g->d_out = nullptr;
+        g->out_cap = 0;
+        SDR_HIP(hipMalloc(&g->d_out, floats * sizeof(float)));
+        g->out_cap = floats;
+    }
+    int rc = gen_device_impl(g, blocks, g->d_out, g->stream);
+    if (rc != SDR_OK) return rc;
+    SDR_HIP(hipMemcpyAsync(out, g->d_out, floats * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    SDR_HIP(hipStreamSynchronize(g->stream));
+    return SDR_OK;
+}
+
+extern "C" void sdr_gen_destroy(sdr_gen_t* g) {
+    if (!g) return;
+    DeviceGuard guard(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->h_phi) (void)hipHostFree(g->h_phi);
+    if (g->d_phi) (void)hipFree(g->d_phi);
+    if (g->d_out) (void)hipFree(g->d_out);
+    if (g->table_free) (void)hipEventDestroy(g->table_free);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
 }
