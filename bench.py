@@ -133,15 +133,22 @@ def main():
     w = 2 if cplx else 1
     st = S.FirState(taps, cplx, channels=channels, device=local_rank)
 
+    from sdr_amd import sharding
     x = torch.empty((channels * n, w), dtype=torch.float32, device=dev)
-    first = rank * n * channels
+    # weak scaling: the global stream is world * n samples (or world * channels
+    # channels); this rank owns one contiguous chunk (one group of channels)
+    first, count = sharding.plan_chunks(world * n * channels, world, n * channels)[rank]
+    assert count == n * channels
     fill_counter_based(x, first)
     y = torch.empty_like(x)
-    if rank > 0 and channels == 1:
-        # prime the history with the left halo of this rank's chunk
-        halo = torch.empty((len(taps) - 1, w), dtype=torch.float32, device=dev)
-        fill_counter_based(halo, first - (len(taps) - 1))
-        st.process_tensor(halo.view(-1) if not cplx else halo)
+    if channels == 1:
+        lo, hl = sharding.halo_range(first, len(taps))
+        if hl:
+            # prime the history with the left halo of this rank's chunk, regenerated
+            # from the counter-based source (no neighbour exchange)
+            halo = torch.empty((hl, w), dtype=torch.float32, device=dev)
+            fill_counter_based(halo, lo)
+            st.process_tensor(halo.view(-1) if not cplx else halo)
     xin = x if cplx else x.view(channels, n) if channels > 1 else x.view(-1)
     yout = y if cplx else y.view(channels, n) if channels > 1 else y.view(-1)
     if cplx and channels > 1:

@@ -1,0 +1,78 @@
+"""Multi-GPU sharding of the FIR path: one process per GPU, no data-path collective.
+
+The path shards two ways:
+  * independent channels: channel c is one stream id with its own filter history;
+    ranks take contiguous groups of channels, nothing is exchanged;
+  * one long stream: rank r owns outputs [start_r, start_r + count_r) and needs the
+    ntaps-1 inputs before start_r (its left halo).  The halo is taken from the
+    SOURCE of the stream (host ring, file, or a regenerable synthetic input), not
+    from the neighbouring GPU, so chunks are independent; the only collective is
+    the optional gather of results.
+The group delay skip of a block (hilbert's (ntaps-1)/2 dropped outputs) applies to
+the global stream start only, i.e. on the rank that owns sample 0.
+"""
+
+
+def plan_chunks(n_total, world, align=1):
+    """Contiguous, ordered, disjoint cover of [0, n_total): list of (start, count),
+    one per rank; every start is a multiple of `align` (the last chunk takes the
+    remainder)."""
+    if world < 1 or n_total < 0 or align < 1:
+        raise ValueError("bad sharding request")
+    units = -(-n_total // align)
+    base, extra = divmod(units, world)
+    out, start = [], 0
+    for r in range(world):
+        cnt = (base + (1 if r < extra else 0)) * align
+        cnt = max(0, min(cnt, n_total - start))
+        out.append((start, cnt))
+        start += cnt
+    return out
+
+
+def plan_channels(channels, world):
+    """Contiguous groups of channels, one per rank: list of (first, count)."""
+    return plan_chunks(channels, world, 1)
+
+
+def halo_range(start, ntaps):
+    """Global sample range [lo, start) a chunk starting at `start` must be primed
+    with (empty for the chunk that owns sample 0: its history is zeros)."""
+    lo = max(0, start - (ntaps - 1))
+    return lo, start - lo
+
+
+def filter_chunk(make_state, source, n_total, ntaps, rank, world, align=1):
+    """Filter this rank's chunk of a stream of n_total samples.
+
+    make_state() -> object with .process(x) (streaming, history carried): the GPU
+    FirState in production.  source(start, count) -> the input samples of that
+    global range.  Returns (start, y) with y = the stream's outputs [start, start+count).
+    """
+    start, count = plan_chunks(n_total, world, align)[rank]
+    st = make_state()
+    lo, hl = halo_range(start, ntaps)
+    if hl:
+        st.process(source(lo, hl))      # prime the history; outputs discarded
+    y = st.process(source(start, count)) if count else source(start, 0)
+    return start, y
+
+
+def gather_chunks(y, dist, dst=0):
+    """Gather every rank's output slice on rank `dst` (torch.distributed, any
+    backend; slices may differ in length).  Returns the list of slices on dst, None
+    elsewhere.  Compute never waits on this: it is result collection only."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([y.shape[0]], dtype=torch.int64, device=y.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+    pad[: y.shape[0]] = y
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [b[:s] for b, s in zip(bufs, sizes)]
