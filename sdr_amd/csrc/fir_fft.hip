@@ -1,0 +1,386 @@
+// fir_fft.hip -- overlap-save streaming FIR with an in-LDS 4096-point FFT, gfx950.
+//
+// Same contract as fir_direct (y[i] = sum_j h[j] x[i-j] over the virtual stream
+// history|input), but the arithmetic is a fast convolution: the direct form costs
+// ntaps packed FMAs per complex sample and is VALU-bound from ~80 taps up
+// (DESIGN.md 4.1); this kernel costs ~50 packed ops per sample whatever the tap
+// count (up to 4096-64 taps), which puts medium and long filters back under the
+// HBM roofline.
+//
+// One workgroup (256 lanes) owns tiles of N = 4096 input samples: halo (>= ntaps-1,
+// multiple of 64) old samples + L = N - halo new ones; it produces L outputs per tile
+// and walks over tiles persistently.  Each lane keeps 16 complex points in VGPRs:
+//
+//   forward (decimation in frequency, natural order in -> digit-reversed out):
+//     n = 256 n2 + 16 n1 + n0,  k = k0 + 16 k1 + 256 k2
+//     A: lane r = 16 n1 + n0 loads x[256 n2 + r] straight from HBM (coalesced 8 B/lane),
+//        DFT16 over n2 -> k0, times W_4096^(r k0)
+//     exchange 1 through LDS ([k0][r], 16-complex pad per k0 row: conflict-free both ways)
+//     B: lane (k0,n0): DFT16 over n1 -> k1, times W_256^(n0 k1)
+//     exchange 2 (16x16 transpose inside each 16-lane group, row stride 17)
+//     C: lane (k0,k1): DFT16 over n0 -> k2        => X[k0 + 16 k1 + 256 k2]
+//   pointwise product with the filter spectrum H/N (held in VGPRs, one load per lane
+//   per kernel), then the mirrored inverse (C', exchange 2', B', exchange 1', A') with
+//   conjugated twiddles, and lane r stores y[256 n2 + r] for the L new positions.
+//
+// The three twiddle sets are per-lane constants kept in registers for the life of the
+// (persistent) workgroup.  Real signals ride two-at-a-time as re/im of one complex
+// FFT (the filter is real-tap, hence linear over that pairing), like in fir_direct.
+//
+// fp32 error: ~3e-7 of the tile's RMS (measured against a float64 convolution), inside
+// the 1e-5 bar; unlike the direct form it is relative to the tile, not to each output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "fir_kernels.h"
+
+namespace sdr_amd {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int FFT_N = 4096;
+constexpr int ROW = 272; // complex elements per k0 row in LDS (256 + 16 pad)
+
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2 add_mi(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + (+i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 add_pi(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// x * w : two packed ops (broadcast / swap / negate are operand modifiers)
+__device__ __forceinline__ f2 cmul(f2 x, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
+    return r;
+}
+// x * conj(w)
+__device__ __forceinline__ f2 cmulc(f2 x, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
+    return r;
+}
+// x * (c, s) with a compile-time constant held in an SGPR pair
+__device__ __forceinline__ f2 cmul_k(f2 x, float c, float s) {
+    const f2 w = {c, s};
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "s"(w), "v"(t));
+    return r;
+}
+
+template <bool INV>
+__device__ __forceinline__ void radix4(f2& x0, f2& x1, f2& x2, f2& x3) {
+    const f2 s0 = x0 + x2, s1 = x0 - x2, s2 = x1 + x3, s3 = x1 - x3;
+    x0 = s0 + s2;
+    x2 = s0 - s2;
+    if (!INV) { x1 = add_mi(s1, s3); x3 = add_pi(s1, s3); }
+    else      { x1 = add_pi(s1, s3); x3 = add_mi(s1, s3); }
+}
+
+// In-place 16-point DFT (INV: inverse, unscaled).  Input v[n] in natural order;
+// output X[k] is left at v[P16(k)], P16(k) = 4*(k&3) + (k>>2).
+__host__ __device__ constexpr int P16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <bool INV>
+__device__ __forceinline__ void dft16(f2 (&v)[16]) {
+    // n = 4a + b: radix-4 over a for every b -> t[b][c] at v[4c + b]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) radix4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // twiddle W16^(b c)
+    constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f; // cos, sin(pi/8)
+    constexpr float C2 = 0.70710678118654752440f;
+    constexpr float sg = INV ? 1.0f : -1.0f; // forward W = exp(-i..): (cos, -sin)
+    v[4 * 1 + 1] = cmul_k(v[4 * 1 + 1], C1, sg * S1);   // W16^1
+    v[4 * 1 + 2] = cmul_k(v[4 * 1 + 2], C2, sg * C2);   // W16^2
+    v[4 * 1 + 3] = cmul_k(v[4 * 1 + 3], S1, sg * C1);   // W16^3
+    v[4 * 2 + 1] = cmul_k(v[4 * 2 + 1], C2, sg * C2);   // W16^2
+    {                                                    // W16^4 = -i (fwd) / +i (inv)
+        const f2 z = {0.0f, 0.0f};
+        v[4 * 2 + 2] = INV ? add_pi(z, v[4 * 2 + 2]) : add_mi(z, v[4 * 2 + 2]);
+    }
+    v[4 * 2 + 3] = cmul_k(v[4 * 2 + 3], -C2, sg * C2);  // W16^6
+    v[4 * 3 + 1] = cmul_k(v[4 * 3 + 1], S1, sg * C1);   // W16^3
+    v[4 * 3 + 2] = cmul_k(v[4 * 3 + 2], -C2, sg * C2);  // W16^6
+    v[4 * 3 + 3] = cmul_k(v[4 * 3 + 3], -C1, -sg * S1); // W16^9
+    // radix-4 over b for every c -> X[c + 4d] at v[4c + d]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) radix4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+__device__ __forceinline__ f2 unit_root(int m, int M) { // exp(-2 pi i m / M)
+    float s, c;
+    sincospif(-2.0f * (float)m / (float)M, &s, &c);
+    return f2{c, s};
+}
+
+} // namespace
+
+// Per-lane constants, computed once per (persistent) workgroup and kept in VGPRs:
+//   TA[k] = W_4096^(tid k), TB[k] = W_256^((tid&15) k), H[k2] = spectrum/N of bin
+//   (tid>>4) + 16 (tid&15) + 256 k2.
+struct LaneConsts {
+    f2 TA[16], TB[16], H[16];
+    __device__ __forceinline__ void init(int tid, const float* hperm) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            TA[k] = unit_root((tid * k) & 4095, 4096);
+            TB[k] = unit_root(((tid & 15) * k) & 255, 256);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) H[k] = reinterpret_cast<const f2*>(hperm)[k * 256 + tid];
+    }
+};
+
+// One tile: v[n2] = x[256 n2 + tid] in, v[P16(n2)] = y[256 n2 + tid] out (circular
+// convolution of the 4096-point tile with the taps).  `after_points_left` is called
+// once the input points have left the registers (the slot where the next tile's
+// loads are issued).
+template <class Hook>
+__device__ __forceinline__ void convolve_tile(f2 (&v)[16], f2* lds, int tid, const LaneConsts& c, Hook&& after_points_left) {
+    const int l16 = tid & 15;
+    f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
+    // ---- forward A: over n2 -> k0, twiddle W_4096^(r k0) -------------------------
+    dft16<false>(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.TA[k]);
+    __syncthreads(); // everyone is done reading the previous tile's rows
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[k * ROW + tid] = v[P16(k)];
+    after_points_left();
+    __syncthreads();
+    // ---- forward B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) -----
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
+    dft16<false>(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.TB[k]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
+    __builtin_amdgcn_wave_barrier();
+    // ---- forward C: lane (k0, k1 = l16), over n0 -> k2 ----------------------------
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) v[n0] = row1[l16 * 17 + n0];
+    dft16<false>(v);
+    // ---- filter: X[k0 + 16 k1 + 256 k2] * H/N -------------------------------------
+    f2 w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], c.H[k]);
+    // ---- inverse C': over k2 -> n0 ------------------------------------------------
+    dft16<true>(w);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) row1[l16 * 17 + n0] = w[P16(n0)];
+    __builtin_amdgcn_wave_barrier();
+    // ---- inverse B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 --------------
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = row1[k * 17 + l16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], c.TB[k]);
+    dft16<true>(v);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) row1[16 * n1 + l16] = v[P16(n1)];
+    __syncthreads();
+    // ---- inverse A': lane r: conj twiddle, over k0 -> n2 --------------------------
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[k * ROW + tid];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], c.TA[k]);
+    dft16<true>(v);
+}
+
+// ---- interior tiles: straight-line, software-pipelined -----------------------------
+// Tiles whose 4096 inputs and all outputs lie inside [0, n): tiles 1 .. full-1 of every
+// channel.  halo = 256*HB is a compile-time constant so that loads and stores are
+// unconditional and the compiler's vmcnt bookkeeping is exact: the next tile's 16
+// loads are issued right after the current points have left the registers and are
+// only waited for at the top of the next iteration, past the current tile's stores.
+template <bool REAL, int HB>
+__global__ __launch_bounds__(256, 2) void fir_fft4096_interior(FftArgs a) {
+    __shared__ __align__(16) f2 lds[16 * ROW];
+    const int tid = threadIdx.x;
+    LaneConsts c;
+    c.init(tid, a.hperm);
+    constexpr int W = REAL ? 1 : 2;
+    constexpr long long L = FFT_N - 256 * HB;
+    constexpr long long per_tile = REAL ? 2 * L : L;
+    const long long inner = a.n / per_tile - 1;          // interior tiles per channel
+    const long long total = inner * a.channels;
+    if (inner <= 0) return;
+
+    // (channel, tile) of this workgroup's current and next tile, advanced without
+    // 64-bit divisions; tt counts interior tiles from 1
+    struct Pos { long long ch, tt; };
+    auto advance = [&](Pos p) {
+        p.tt += gridDim.x;
+        while (p.tt > inner) { p.tt -= inner; ++p.ch; }
+        return p;
+    };
+    auto in_ptr = [&](Pos p) -> const float* {            // wave-uniform pointer to x[s0]
+        return a.in + (p.ch * a.in_stride + p.tt * per_tile - 256 * HB) * W;
+    };
+    auto load = [&](const float* p0, f2 (&dst)[16]) {
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            if (REAL) {
+                const float* q = p0 + 256 * n2;
+                dst[n2] = f2{__builtin_nontemporal_load(q + tid), __builtin_nontemporal_load(q + L + tid)};
+            } else {
+                dst[n2] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
+            }
+        }
+    };
+
+    if ((long long)blockIdx.x >= total) return;
+    Pos cur{0, 0};
+    cur.tt = 1 + blockIdx.x;
+    while (cur.tt > inner) { cur.tt -= inner; ++cur.ch; }
+    f2 nx[16];
+    load(in_ptr(cur), nx);
+
+    auto body = [&]() {
+        f2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = nx[i];
+        // past the end the workgroup re-loads its own tile (harmless): keeps the body branch-free
+        Pos nxt = advance(cur);
+        if (nxt.ch >= a.channels) nxt = cur;
+        const float* pn = in_ptr(nxt);
+        if (a.ablate & 1) load(pn, nx);
+        else convolve_tile(v, lds, tid, c, [&] { load(pn, nx); });
+        float* q0 = a.out + (cur.ch * a.out_stride + cur.tt * per_tile - 256 * HB) * W; // &y[-halo] of the tile
+#pragma unroll
+        for (int n2 = HB; n2 < 16; ++n2) {
+            const f2 y = v[P16(n2)];
+            if (REAL) {
+                float* q = q0 + 256 * n2;
+                __builtin_nontemporal_store(y.x, q + tid);
+                __builtin_nontemporal_store(y.y, q + L + tid);
+            } else {
+                __builtin_nontemporal_store(y, reinterpret_cast<f2*>(q0 + 512 * n2) + tid);
+            }
+        }
+        cur = advance(cur);
+    };
+    // First tile peeled so that the loop header sees the same queue of outstanding
+    // memory operations from both of its predecessors (16 loads, then this tile's
+    // stores): the waits at the top of the loop then cover the loads only.
+    body();
+    while (cur.ch < a.channels) body();
+}
+
+// ---- edge tiles: the first tile of every channel (reads the carried history) and the
+// tiles from the last full one on (partial outputs); also every tile of a short call.
+// Bounds-checked, runtime halo, no pipelining.
+template <bool REAL>
+__global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
+    __shared__ __align__(16) f2 lds[16 * ROW];
+    const int tid = threadIdx.x;
+    LaneConsts c;
+    c.init(tid, a.hperm);
+    constexpr int W = REAL ? 1 : 2;
+    const int halo = a.halo;
+    const long long L = FFT_N - halo;
+    const long long per_tile = REAL ? 2 * L : L;
+    const long long tiles_per_ch = (a.n + per_tile - 1) / per_tile;
+    // interior tiles [1, full) are skipped when the interior kernel handles them
+    const long long full = a.n / per_tile;
+    const long long skip_lo = 1, skip_hi = a.interior_split && full > 1 ? full : 1;
+    const long long edge_per_ch = tiles_per_ch - (skip_hi - skip_lo);
+    const long long total = edge_per_ch * a.channels;
+
+    for (long long e = blockIdx.x; e < total; e += gridDim.x) {
+        const long long ch = e / edge_per_ch;
+        long long tt = e - ch * edge_per_ch;
+        if (tt >= skip_lo) tt += skip_hi - skip_lo;
+        const float* in = a.in + ch * a.in_stride * W;
+        const float* hist = a.hist + ch * (long long)a.hist_len * W;
+        float* out = a.out + ch * a.out_stride * W;
+        const long long o0 = tt * per_tile; // first output of the tile
+        const long long s0 = o0 - halo;     // first input (virtual stream index)
+        auto sample = [&](long long m, int k) -> float { // virtual stream: history | input | 0
+            if (m < 0) { const long long h = a.hist_len + m; return h >= 0 ? hist[h * W + k] : 0.0f; }
+            return m < a.n ? in[m * W + k] : 0.0f;
+        };
+        f2 v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const long long m = s0 + 256 * n2 + tid;
+            if (REAL) v[n2] = f2{sample(m, 0), sample(m + L, 0)};
+            else v[n2] = f2{sample(m, 0), sample(m, 1)};
+        }
+        convolve_tile(v, lds, tid, c, [] {});
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int m = 256 * n2 + tid - halo;
+            if (m < 0) continue;
+            const long long o = o0 + m;
+            const f2 y = v[P16(n2)];
+            if (REAL) {
+                if (o < a.n) out[o] = y.x;
+                if (o + L < a.n) out[o + L] = y.y;
+            } else if (o < a.n) {
+                *reinterpret_cast<f2*>(out + 2 * o) = y;
+            }
+        }
+    }
+}
+
+template <bool REAL>
+static hipError_t launch_interior(const FftArgs& a, long long grid, hipStream_t stream) {
+    switch (a.halo / 256) {
+        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// halo (old samples per tile) for a tap count: 256 * {1,2,4,8}; 0 = too many taps
+int fir_fft_halo(size_t ntaps) {
+    for (int hb : {1, 2, 4, 8})
+        if (ntaps <= (size_t)256 * hb + 1) return 256 * hb;
+    return 0;
+}
+
+hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStream_t stream) {
+    if (a0.n == 0 || a0.channels == 0) return hipSuccess;
+    FftArgs a = a0;
+    const long long L = FFT_N - a.halo;
+    const long long per_tile = real ? 2 * L : L;
+    const long long tiles_per_ch = (a.n + per_tile - 1) / per_tile;
+    const long long inner = a.n / per_tile - 1;
+    a.interior_split = inner > 0 ? 1 : 0;
+    hipError_t e = hipSuccess;
+    if (inner > 0) {
+        long long grid = inner * a.channels < grid_blocks ? inner * a.channels : grid_blocks;
+        e = real ? launch_interior<true>(a, grid, stream) : launch_interior<false>(a, grid, stream);
+        if (e != hipSuccess) return e;
+    }
+    const long long edge = (tiles_per_ch - (inner > 0 ? inner : 0)) * a.channels;
+    if (edge > 0) {
+        long long grid = edge < grid_blocks ? edge : grid_blocks;
+        if (real) hipLaunchKernelGGL(fir_fft4096_edge<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(fir_fft4096_edge<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+const char* fir_fft_kernel_name(bool real) { return real ? "fir_fft4096_interior<REAL>" : "fir_fft4096_interior<COMPLEX>"; }
+
+} // namespace sdr_amd

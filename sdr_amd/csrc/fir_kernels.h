@@ -30,6 +30,25 @@ struct KernelInfo {
     bool real;
 };
 
+// overlap-save FFT path (fir_fft.hip)
+struct FftArgs {
+    const float* in;
+    float* out;
+    const float* hist;    // [channels][hist_len]
+    const float* hperm;   // 4096 complex: H[k]/N stored at [k2*256 + 16*k0 + k1], k = k0 + 16 k1 + 256 k2
+    long long n;
+    long long in_stride;
+    long long out_stride;
+    long long channels;
+    int halo;             // old samples per tile: >= ntaps-1; 256 * {1,2,4,8}
+    int hist_len;         // >= halo
+    int ablate;           // diagnostics (SDR_AMD_FFT_ABLATE): 1 = skip the arithmetic (memory pattern only)
+    int interior_split;   // set by launch_fir_fft: the interior kernel handles tiles [1, n/per_tile)
+};
+hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
+const char* fir_fft_kernel_name(bool real);
+int fir_fft_halo(size_t ntaps);
+
 const KernelInfo* find_kernel(int R, int stride, bool real);
 size_t kernel_lds_bytes(const KernelInfo& k, int nchunks);
 hipError_t prepare_kernel(const KernelInfo& k, int nchunks);

@@ -70,6 +70,10 @@ struct sdr_fir {
     int hist_len = 0;
     int shift = 0;
     float* d_taps = nullptr;
+    bool use_fft = false;   // overlap-save FFT kernel instead of the direct form
+    int fft_halo = 0;
+    int fft_grid = 0;
+    float* d_hperm = nullptr;
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     hipStream_t stream = nullptr; // used by the host-buffer entry points
@@ -126,7 +130,14 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     else if (even_zero && !odd_zero) stride = 2, shift = 1;
     if (env_int("SDR_AMD_DENSE", 0)) stride = 1, shift = 0;
 
-    int R = env_int("SDR_AMD_R", stride == 2 ? 16 : 8);
+    // Path choice.  Direct form: ntaps (or ntaps/2 with the Hilbert structure) packed
+    // FMAs per complex sample; overlap-save FFT (N = 4096): ~50 packed ops per sample
+    // times 4096/(4096-halo).  SDR_AMD_FFT=0/1 forces the choice.
+    const int fft_halo = fir_fft_halo(ntaps);
+    bool use_fft = ntaps >= (stride == 2 ? 192u : 64u) && fft_halo > 0;
+    if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_halo > 0;
+
+    int R = env_int("SDR_AMD_R", 8);
     if (R != 4 && R != 8 && R != 16) return fail(SDR_ERR_INVALID, "SDR_AMD_R must be 4, 8 or 16");
     const KernelInfo* k = find_kernel(R, stride, sample_kind == SDR_REAL);
     if (!k) return fail(SDR_ERR_INVALID, "sdr_fir_create: no kernel for this configuration");
@@ -152,6 +163,11 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     f->nchunks = nchunks;
     f->shift = shift;
     f->hist_len = nchunks * R + 4;
+    f->use_fft = use_fft;
+    if (use_fft) {
+        f->fft_halo = fft_halo;
+        f->hist_len = fft_halo + 4;
+    }
 
     DeviceGuard guard(device);
     int rc = SDR_OK;
@@ -170,6 +186,35 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     if ((e = hipMalloc(&f->d_hist[1], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
     if ((e = hipMemcpy(f->d_taps, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(taps)");
+    if (use_fft) {
+        // Filter spectrum H[k] = (1/N) sum_j h[j] exp(-2 pi i j k / N), N = 4096, in
+        // double on the host, stored in the order the kernel's lanes consume it.
+        const int N = 4096;
+        std::vector<double> cs(N), sn(N);
+        for (int m = 0; m < N; ++m) {
+            cs[m] = std::cos(2.0 * M_PI * m / N);
+            sn[m] = std::sin(2.0 * M_PI * m / N);
+        }
+        std::vector<float> hp(2 * N);
+        for (int k = 0; k < N; ++k) {
+            double re = 0.0, im = 0.0;
+            for (size_t j = 0; j < ntaps; ++j) {
+                const int m = (int)((j * (size_t)k) & (N - 1));
+                re += taps[j] * cs[m];
+                im -= taps[j] * sn[m];
+            }
+            const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
+            const int pos = k2 * 256 + 16 * k0 + k1;
+            hp[2 * pos] = (float)(re / N);
+            hp[2 * pos + 1] = (float)(im / N);
+        }
+        if ((e = hipMalloc(&f->d_hperm, hp.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
+        if ((e = hipMemcpy(f->d_hperm, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+            return bail(e, "hipMemcpy(spectrum)");
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", 2);
+    }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
@@ -189,6 +234,7 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (f->d_taps) (void)hipFree(f->d_taps);
+    if (f->d_hperm) (void)hipFree(f->d_hperm);
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
     if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -203,6 +249,26 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
     const size_t wbytes = f->w * sizeof(float);
     if (((uintptr_t)d_in % wbytes) || ((uintptr_t)d_out % wbytes))
         return fail(SDR_ERR_INVALID, "sdr_fir_process_device: buffers must be aligned to the sample size");
+    if (f->use_fft) {
+        FftArgs fa;
+        fa.in = d_in;
+        fa.out = d_out;
+        fa.hist = f->d_hist[f->cur];
+        fa.hperm = f->d_hperm;
+        fa.n = (long long)n;
+        fa.in_stride = (long long)in_stride;
+        fa.out_stride = (long long)out_stride;
+        fa.channels = (long long)f->channels;
+        fa.halo = f->fft_halo;
+        fa.hist_len = f->hist_len;
+        fa.interior_split = 0;
+        fa.ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
+        SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
+        SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur],
+                                     f->d_hist[f->cur ^ 1], f->hist_len, f->w, f->channels, stream));
+        f->cur ^= 1;
+        return SDR_OK;
+    }
     FirArgs a;
     a.in = d_in;
     a.out = d_out;
@@ -306,8 +372,11 @@ extern "C" int sdr_fir_reset(sdr_fir_t* f) {
 }
 
 extern "C" size_t sdr_fir_ntaps(const sdr_fir_t* f) { return f ? f->ntaps : 0; }
-extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? f->k->stride : 0; }
-extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) { return f ? f->k->name : ""; }
+extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? (f->use_fft ? 1 : f->k->stride) : 0; }
+extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) {
+    if (!f) return "";
+    return f->use_fft ? fir_fft_kernel_name(f->kind == SDR_REAL) : f->k->name;
+}
 
 extern "C" void* sdr_host_alloc(size_t bytes) {
     clear_error();

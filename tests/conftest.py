@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch first: its bundled HIP runtime must be the one loaded in this process
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -60,8 +60,8 @@ def test_single_call_vs_oracle(kind, ntaps, cplx):
     n = 20011  # ragged: not a multiple of any tile size
     x = rand(rng, n, cplx)
     st = sdr_amd.FirState(taps, cplx)
-    if kind == "hilbert" and ntaps >= 8:
-        assert st.tap_stride == 2, "Hilbert taps must select the zero-skipping kernel"
+    if kind == "hilbert" and 8 <= ntaps < 192:
+        assert st.tap_stride == 2, "short Hilbert taps must select the zero-skipping direct kernel"
     y = sdr_amd.fir(st, x)
     ref = O.fir(taps, x)
     assert y.shape == ref.shape and y.dtype == ref.dtype
@@ -199,7 +199,12 @@ def test_linearity_and_impulse_full_size():
     y = st.process_tensor(x)
     torch.cuda.synchronize()
     t = torch.from_numpy(taps).cuda()
+    # exact for the direct form; the overlap-save FFT path reproduces the taps to
+    # fp32 FFT rounding (a few 1e-7 of the largest tap)
+    atol = 2e-6 * float(t.abs().max())
     for p in pos[:: max(1, len(pos) // 16)].tolist() + [int(pos[-1])]:
         seg = y[p:p + 127]
-        assert torch.equal(seg[:, 0], t) and torch.equal(seg[:, 1], -2.0 * t), p
-    assert float(y.abs().sum()) == pytest.approx(float(len(pos) * 3.0 * t.abs().sum()), rel=1e-4)
+        assert float((seg[:, 0] - t).abs().max()) <= atol, p
+        assert float((seg[:, 1] + 2.0 * t).abs().max()) <= 2 * atol, p
+    # nothing leaks between the impulses (no sample dropped, duplicated or moved)
+    assert float(y.abs().sum()) == pytest.approx(float(len(pos) * 3.0 * t.abs().sum()), rel=2e-3)
