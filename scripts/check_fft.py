@@ -7,7 +7,7 @@ def rel(a, b):
     a = a.astype(np.complex128); b = b.astype(np.complex128)
     return np.max(np.abs(a - b)) / np.sqrt(np.mean(np.abs(b) ** 2))
 for cplx in (True, False):
-    for nt, kind in ((127, "lp"), (64, "lp"), (255, "lp"), (1000, "lp"), (127, "hil"), (3000, "lp")):
+    for nt, kind in ((127, "lp"), (64, "lp"), (255, "lp"), (1000, "lp"), (127, "hil"), (3000, "lp"), (4095, "lp"), (4096, "lp"), (9001, "lp")):
         taps = sdr_amd.fir_lowpass(nt, 0.1) if kind == "lp" else sdr_amd.hilbert(nt)
         n = 50001
         x = rng.uniform(-1, 1, n * (2 if cplx else 1)).astype(np.float32)

@@ -24,18 +24,26 @@ for f in find("trace/**/*kernel_stats.csv"):
             print("%-70s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
                 row["Name"][:70], row["Calls"], row["TotalDurationNs"], row["AverageNs"], row["Percentage"]))
 
+# dominant FIR kernel = the fir_* kernel with the largest total time in the trace
+dominant, best = "fir_", -1.0
+for f in find("trace/**/*kernel_stats.csv"):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "fir_" in row["Name"] and "carry" not in row["Name"] and float(row["TotalDurationNs"]) > best:
+                best, dominant = float(row["TotalDurationNs"]), row["Name"].split("(")[0]
+print("== dominant kernel:", dominant)
 res = {}
 for key, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
     vals = []
     for f in find(pat):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if "fir_direct" in row.get("Kernel_Name", "") and row.get("Counter_Name") == key:
+                if dominant in row.get("Kernel_Name", "") and row.get("Counter_Name") == key:
                     vals.append(float(row["Counter_Value"]))
     if vals:
         vals = vals[1:] or vals  # drop the warm-up launch
         res[key] = sum(vals) / len(vals)
-print("== PMC (per fir_direct launch, raw KiB) ==", res)
+print("== PMC (per launch of the dominant kernel, raw KiB) ==", res)
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     rd = res["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE = 1/2 of streamed bytes
     wr = res["WRITE_SIZE"] * 1024

@@ -131,35 +131,36 @@ __device__ __forceinline__ f2 unit_root(int m, int M) { // exp(-2 pi i m / M)
 //   (tid>>4) + 16 (tid&15) + 256 k2.
 struct LaneConsts {
     f2 TA[16], TB[16], H[16];
-    __device__ __forceinline__ void init(int tid, const float* hperm) {
+    __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum) {
 #pragma unroll
         for (int k = 1; k < 16; ++k) {
             TA[k] = unit_root((tid * k) & 4095, 4096);
             TB[k] = unit_root(((tid & 15) * k) & 255, 256);
         }
+        if (with_spectrum) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) H[k] = reinterpret_cast<const f2*>(hperm)[k * 256 + tid];
+            for (int k = 0; k < 16; ++k) H[k] = reinterpret_cast<const f2*>(hperm)[k * 256 + tid];
+        }
     }
 };
 
-// One tile: v[n2] = x[256 n2 + tid] in, v[P16(n2)] = y[256 n2 + tid] out (circular
-// convolution of the 4096-point tile with the taps).  `after_points_left` is called
-// once the input points have left the registers (the slot where the next tile's
-// loads are issued).
+// Forward transform of one tile: v[n2] = x[256 n2 + tid] in, X[(tid>>4) + 16 (tid&15)
+// + 256 k2] left at v[P16(k2)].  `after_points_left` runs once the input points have
+// left the registers (the slot where the next tile's loads are issued).
 template <class Hook>
-__device__ __forceinline__ void convolve_tile(f2 (&v)[16], f2* lds, int tid, const LaneConsts& c, Hook&& after_points_left) {
+__device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const LaneConsts& c, Hook&& after_points_left) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
-    // ---- forward A: over n2 -> k0, twiddle W_4096^(r k0) -------------------------
+    // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
     dft16<false>(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.TA[k]);
-    __syncthreads(); // everyone is done reading the previous tile's rows
+    __syncthreads(); // everyone is done reading the rows (previous tile / previous pass)
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[k * ROW + tid] = v[P16(k)];
     after_points_left();
     __syncthreads();
-    // ---- forward B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) -----
+    // ---- B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) --------------
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
     dft16<false>(v);
@@ -169,63 +170,75 @@ __device__ __forceinline__ void convolve_tile(f2 (&v)[16], f2* lds, int tid, con
 #pragma unroll
     for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
     __builtin_amdgcn_wave_barrier();
-    // ---- forward C: lane (k0, k1 = l16), over n0 -> k2 ----------------------------
+    // ---- C: lane (k0, k1 = l16), over n0 -> k2 ------------------------------------
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) v[n0] = row1[l16 * 17 + n0];
     dft16<false>(v);
-    // ---- filter: X[k0 + 16 k1 + 256 k2] * H/N -------------------------------------
-    f2 w[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], c.H[k]);
-    // ---- inverse C': over k2 -> n0 ------------------------------------------------
+}
+
+// Inverse transform: w[k2] = Y[(tid>>4) + 16 (tid&15) + 256 k2] in (natural k2 order),
+// y[256 n2 + tid] left at w[P16(n2)].
+__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const LaneConsts& c) {
+    const int l16 = tid & 15;
+    f2* row1 = lds + (tid >> 4) * ROW;
+    // ---- C': over k2 -> n0 --------------------------------------------------------
     dft16<true>(w);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) row1[l16 * 17 + n0] = w[P16(n0)];
     __builtin_amdgcn_wave_barrier();
-    // ---- inverse B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 --------------
+    // ---- B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 ----------------------
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = row1[k * 17 + l16];
+    for (int k = 0; k < 16; ++k) w[k] = row1[k * 17 + l16];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], c.TB[k]);
-    dft16<true>(v);
+    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.TB[k]);
+    dft16<true>(w);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) row1[16 * n1 + l16] = v[P16(n1)];
+    for (int n1 = 0; n1 < 16; ++n1) row1[16 * n1 + l16] = w[P16(n1)];
     __syncthreads();
-    // ---- inverse A': lane r: conj twiddle, over k0 -> n2 --------------------------
+    // ---- A': lane r: conj twiddle, over k0 -> n2 ----------------------------------
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[k * ROW + tid];
+    for (int k = 0; k < 16; ++k) w[k] = lds[k * ROW + tid];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmulc(v[k], c.TA[k]);
-    dft16<true>(v);
+    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.TA[k]);
+    dft16<true>(w);
+}
+
+// Filter spectrum of partition p, bin (tid>>4) + 16 (tid&15) + 256 k2, from L2.
+__device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int tid) {
+    return reinterpret_cast<const f2*>(hperm)[p * FFT_N + k2 * 256 + tid];
 }
 
 // ---- interior tiles: straight-line, software-pipelined -----------------------------
-// Tiles whose 4096 inputs and all outputs lie inside [0, n): tiles 1 .. full-1 of every
-// channel.  halo = 256*HB is a compile-time constant so that loads and stores are
-// unconditional and the compiler's vmcnt bookkeeping is exact: the next tile's 16
-// loads are issued right after the current points have left the registers and are
-// only waited for at the top of the next iteration, past the current tile's stores.
-template <bool REAL, int HB>
+// Tiles whose inputs and outputs all lie inside [0, n).  halo = 256*HB is a
+// compile-time constant so that loads and stores are unconditional and the compiler's
+// vmcnt bookkeeping is exact: the next tile's 16 loads are issued right after the
+// current points have left the registers and are only waited for at the top of the
+// next iteration, past the current tile's stores.
+//
+// LONG = uniformly partitioned overlap-save for more than 2049 taps: hop L = 2048,
+// the filter is cut into `parts` pieces of 2048 taps, Y_b = sum_p X_(b-p) H_p; the
+// windows b-1.. are re-read (L2) and re-transformed, spectra H_p come from L2.
+template <bool REAL, int HB, bool LONG>
 __global__ __launch_bounds__(256, 2) void fir_fft4096_interior(FftArgs a) {
+    static_assert(!LONG || HB == 8, "partitioned mode uses hop 2048");
     __shared__ __align__(16) f2 lds[16 * ROW];
     const int tid = threadIdx.x;
     LaneConsts c;
-    c.init(tid, a.hperm);
+    c.init(tid, a.hperm, !LONG);
     constexpr int W = REAL ? 1 : 2;
     constexpr long long L = FFT_N - 256 * HB;
     constexpr long long per_tile = REAL ? 2 * L : L;
-    const long long inner = a.n / per_tile - 1;          // interior tiles per channel
+    const long long inner = a.t_hi - a.t_lo;             // interior tiles per channel
     const long long total = inner * a.channels;
-    if (inner <= 0) return;
 
     // (channel, tile) of this workgroup's current and next tile, advanced without
-    // 64-bit divisions; tt counts interior tiles from 1
+    // 64-bit divisions; tt counts tiles of the channel from a.t_lo
     struct Pos { long long ch, tt; };
     auto advance = [&](Pos p) {
         p.tt += gridDim.x;
-        while (p.tt > inner) { p.tt -= inner; ++p.ch; }
+        while (p.tt >= a.t_hi) { p.tt -= inner; ++p.ch; }
         return p;
     };
     auto in_ptr = [&](Pos p) -> const float* {            // wave-uniform pointer to x[s0]
@@ -243,10 +256,10 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_interior(FftArgs a) {
         }
     };
 
-    if ((long long)blockIdx.x >= total) return;
+    if (inner <= 0 || (long long)blockIdx.x >= total) return;
     Pos cur{0, 0};
-    cur.tt = 1 + blockIdx.x;
-    while (cur.tt > inner) { cur.tt -= inner; ++cur.ch; }
+    cur.tt = a.t_lo + blockIdx.x;
+    while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
     f2 nx[16];
     load(in_ptr(cur), nx);
 
@@ -258,12 +271,32 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_interior(FftArgs a) {
         Pos nxt = advance(cur);
         if (nxt.ch >= a.channels) nxt = cur;
         const float* pn = in_ptr(nxt);
-        if (a.ablate & 1) load(pn, nx);
-        else convolve_tile(v, lds, tid, c, [&] { load(pn, nx); });
+        f2 w[16];
+        if (a.ablate & 1) {
+            load(pn, nx);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[P16(k)] = v[k];
+        } else {
+            forward_tile(v, lds, tid, c, [&] { load(pn, nx); });
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
+            if (LONG) {
+                for (int p = 1; p < a.parts; ++p) {
+                    load(in_ptr(cur) - (long long)p * 2048 * W, v); // window b-p (L2 resident)
+                    forward_tile(v, lds, tid, c, [] {});
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const f2 t = cmul(v[P16(k)], spectrum(a.hperm, p, k, tid));
+                        w[k] += t;
+                    }
+                }
+            }
+            inverse_tile(w, lds, tid, c);
+        }
         float* q0 = a.out + (cur.ch * a.out_stride + cur.tt * per_tile - 256 * HB) * W; // &y[-halo] of the tile
 #pragma unroll
         for (int n2 = HB; n2 < 16; ++n2) {
-            const f2 y = v[P16(n2)];
+            const f2 y = w[P16(n2)];
             if (REAL) {
                 float* q = q0 + 256 * n2;
                 __builtin_nontemporal_store(y.x, q + tid);
@@ -281,53 +314,60 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_interior(FftArgs a) {
     while (cur.ch < a.channels) body();
 }
 
-// ---- edge tiles: the first tile of every channel (reads the carried history) and the
-// tiles from the last full one on (partial outputs); also every tile of a short call.
-// Bounds-checked, runtime halo, no pipelining.
+// ---- edge tiles: the first tile(s) of every channel (they read the carried history)
+// and the tiles from the last full one on (partial outputs); also every tile of a
+// short call.  Bounds-checked, runtime halo / parts, no pipelining.
 template <bool REAL>
 __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * ROW];
     const int tid = threadIdx.x;
     LaneConsts c;
-    c.init(tid, a.hperm);
+    c.init(tid, a.hperm, false);
     constexpr int W = REAL ? 1 : 2;
     const int halo = a.halo;
     const long long L = FFT_N - halo;
     const long long per_tile = REAL ? 2 * L : L;
     const long long tiles_per_ch = (a.n + per_tile - 1) / per_tile;
-    // interior tiles [1, full) are skipped when the interior kernel handles them
-    const long long full = a.n / per_tile;
-    const long long skip_lo = 1, skip_hi = a.interior_split && full > 1 ? full : 1;
-    const long long edge_per_ch = tiles_per_ch - (skip_hi - skip_lo);
+    const long long skipped = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0; // handled by the interior kernel
+    const long long edge_per_ch = tiles_per_ch - skipped;
     const long long total = edge_per_ch * a.channels;
 
     for (long long e = blockIdx.x; e < total; e += gridDim.x) {
         const long long ch = e / edge_per_ch;
         long long tt = e - ch * edge_per_ch;
-        if (tt >= skip_lo) tt += skip_hi - skip_lo;
+        if (skipped && tt >= a.t_lo) tt += skipped;
         const float* in = a.in + ch * a.in_stride * W;
         const float* hist = a.hist + ch * (long long)a.hist_len * W;
         float* out = a.out + ch * a.out_stride * W;
         const long long o0 = tt * per_tile; // first output of the tile
-        const long long s0 = o0 - halo;     // first input (virtual stream index)
         auto sample = [&](long long m, int k) -> float { // virtual stream: history | input | 0
             if (m < 0) { const long long h = a.hist_len + m; return h >= 0 ? hist[h * W + k] : 0.0f; }
             return m < a.n ? in[m * W + k] : 0.0f;
         };
-        f2 v[16];
+        f2 w[16];
+        for (int p = 0; p < a.parts; ++p) {
+            const long long s0 = o0 - halo - (long long)p * 2048; // first input of window b-p
+            f2 v[16];
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
-            const long long m = s0 + 256 * n2 + tid;
-            if (REAL) v[n2] = f2{sample(m, 0), sample(m + L, 0)};
-            else v[n2] = f2{sample(m, 0), sample(m, 1)};
+            for (int n2 = 0; n2 < 16; ++n2) {
+                const long long m = s0 + 256 * n2 + tid;
+                if (REAL) v[n2] = f2{sample(m, 0), sample(m + L, 0)};
+                else v[n2] = f2{sample(m, 0), sample(m, 1)};
+            }
+            forward_tile(v, lds, tid, c, [] {});
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const f2 t = cmul(v[P16(k)], spectrum(a.hperm, p, k, tid));
+                w[k] = p == 0 ? t : w[k] + t;
+            }
         }
-        convolve_tile(v, lds, tid, c, [] {});
+        inverse_tile(w, lds, tid, c);
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             const int m = 256 * n2 + tid - halo;
             if (m < 0) continue;
             const long long o = o0 + m;
-            const f2 y = v[P16(n2)];
+            const f2 y = w[P16(n2)];
             if (REAL) {
                 if (o < a.n) out[o] = y.x;
                 if (o + L < a.n) out[o + L] = y.y;
@@ -340,21 +380,29 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
 
 template <bool REAL>
 static hipError_t launch_interior(const FftArgs& a, long long grid, hipStream_t stream) {
+    const dim3 g((unsigned)grid), b(256);
+    if (a.parts > 1) {
+        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true>), g, b, 0, stream, a);
+        return hipGetLastError();
+    }
     switch (a.halo / 256) {
-        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8>), dim3((unsigned)grid), dim3(256), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false>), g, b, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-// halo (old samples per tile) for a tap count: 256 * {1,2,4,8}; 0 = too many taps
-int fir_fft_halo(size_t ntaps) {
+// Tiling for a tap count: halo = 256 * {1,2,4,8} old samples per tile for up to 2049
+// taps (one spectrum); beyond that hop 2048 with ceil(ntaps/2048) partitions.
+void fir_fft_plan(size_t ntaps, int* halo, int* parts) {
+    *parts = 1;
     for (int hb : {1, 2, 4, 8})
-        if (ntaps <= (size_t)256 * hb + 1) return 256 * hb;
-    return 0;
+        if (ntaps <= (size_t)256 * hb + 1) { *halo = 256 * hb; return; }
+    *halo = 2048;
+    *parts = (int)((ntaps + 2047) / 2048);
 }
 
 hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStream_t stream) {
@@ -363,15 +411,19 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     const long long L = FFT_N - a.halo;
     const long long per_tile = real ? 2 * L : L;
     const long long tiles_per_ch = (a.n + per_tile - 1) / per_tile;
-    const long long inner = a.n / per_tile - 1;
-    a.interior_split = inner > 0 ? 1 : 0;
+    // interior tiles: every input (all partitions) at index >= 0, every output < n
+    const long long lead = a.parts > 1 ? (long long)a.parts * 2048 : a.halo;
+    a.t_lo = (lead + per_tile - 1) / per_tile;
+    a.t_hi = a.n / per_tile;
+    const long long inner = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0;
+    if (inner == 0) a.t_lo = a.t_hi = 0;
     hipError_t e = hipSuccess;
     if (inner > 0) {
         long long grid = inner * a.channels < grid_blocks ? inner * a.channels : grid_blocks;
         e = real ? launch_interior<true>(a, grid, stream) : launch_interior<false>(a, grid, stream);
         if (e != hipSuccess) return e;
     }
-    const long long edge = (tiles_per_ch - (inner > 0 ? inner : 0)) * a.channels;
+    const long long edge = (tiles_per_ch - inner) * a.channels;
     if (edge > 0) {
         long long grid = edge < grid_blocks ? edge : grid_blocks;
         if (real) hipLaunchKernelGGL(fir_fft4096_edge<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);

@@ -35,7 +35,7 @@ struct FftArgs {
     const float* in;
     float* out;
     const float* hist;    // [channels][hist_len]
-    const float* hperm;   // 4096 complex: H[k]/N stored at [k2*256 + 16*k0 + k1], k = k0 + 16 k1 + 256 k2
+    const float* hperm;   // parts x 4096 complex: H_p[k]/N stored at [p*4096 + k2*256 + 16*k0 + k1], k = k0 + 16 k1 + 256 k2
     long long n;
     long long in_stride;
     long long out_stride;
@@ -43,11 +43,12 @@ struct FftArgs {
     int halo;             // old samples per tile: >= ntaps-1; 256 * {1,2,4,8}
     int hist_len;         // >= halo
     int ablate;           // diagnostics (SDR_AMD_FFT_ABLATE): 1 = skip the arithmetic (memory pattern only)
-    int interior_split;   // set by launch_fir_fft: the interior kernel handles tiles [1, n/per_tile)
+    int parts;            // filter partitions of 2048 taps (1 = plain overlap-save)
+    long long t_lo, t_hi; // set by launch_fir_fft: tiles [t_lo, t_hi) of each channel go to the interior kernel
 };
 hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
 const char* fir_fft_kernel_name(bool real);
-int fir_fft_halo(size_t ntaps);
+void fir_fft_plan(size_t ntaps, int* halo, int* parts);
 
 const KernelInfo* find_kernel(int R, int stride, bool real);
 size_t kernel_lds_bytes(const KernelInfo& k, int nchunks);

@@ -72,6 +72,7 @@ struct sdr_fir {
     float* d_taps = nullptr;
     bool use_fft = false;   // overlap-save FFT kernel instead of the direct form
     int fft_halo = 0;
+    int fft_parts = 1;
     int fft_grid = 0;
     float* d_hperm = nullptr;
     float* d_hist[2] = {nullptr, nullptr};
@@ -133,9 +134,10 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     // Path choice.  Direct form: ntaps (or ntaps/2 with the Hilbert structure) packed
     // FMAs per complex sample; overlap-save FFT (N = 4096): ~50 packed ops per sample
     // times 4096/(4096-halo).  SDR_AMD_FFT=0/1 forces the choice.
-    const int fft_halo = fir_fft_halo(ntaps);
-    bool use_fft = ntaps >= (stride == 2 ? 192u : 64u) && fft_halo > 0;
-    if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_halo > 0;
+    int fft_halo = 0, fft_parts = 1;
+    fir_fft_plan(ntaps, &fft_halo, &fft_parts);
+    bool use_fft = ntaps >= (stride == 2 ? 100u : 64u) && fft_parts <= 64;
+    if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_parts <= 64;
 
     int R = env_int("SDR_AMD_R", 8);
     if (R != 4 && R != 8 && R != 16) return fail(SDR_ERR_INVALID, "SDR_AMD_R must be 4, 8 or 16");
@@ -166,7 +168,8 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     f->use_fft = use_fft;
     if (use_fft) {
         f->fft_halo = fft_halo;
-        f->hist_len = fft_halo + 4;
+        f->fft_parts = fft_parts;
+        f->hist_len = (fft_parts > 1 ? fft_parts * 2048 : fft_halo) + 4;
     }
 
     DeviceGuard guard(device);
@@ -195,18 +198,23 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
             cs[m] = std::cos(2.0 * M_PI * m / N);
             sn[m] = std::sin(2.0 * M_PI * m / N);
         }
-        std::vector<float> hp(2 * N);
-        for (int k = 0; k < N; ++k) {
-            double re = 0.0, im = 0.0;
-            for (size_t j = 0; j < ntaps; ++j) {
-                const int m = (int)((j * (size_t)k) & (N - 1));
-                re += taps[j] * cs[m];
-                im -= taps[j] * sn[m];
+        // partition p holds taps [p*2048, p*2048+2048) (all taps when parts == 1)
+        const size_t plen = fft_parts > 1 ? 2048 : ntaps;
+        std::vector<float> hp((size_t)2 * N * fft_parts);
+        for (int p = 0; p < fft_parts; ++p) {
+            const size_t j0 = (size_t)p * plen, j1 = std::min(ntaps, j0 + plen);
+            for (int k = 0; k < N; ++k) {
+                double re = 0.0, im = 0.0;
+                for (size_t j = j0; j < j1; ++j) {
+                    const int m = (int)(((j - j0) * (size_t)k) & (N - 1));
+                    re += taps[j] * cs[m];
+                    im -= taps[j] * sn[m];
+                }
+                const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
+                const size_t pos = (size_t)p * N + k2 * 256 + 16 * k0 + k1;
+                hp[2 * pos] = (float)(re / N);
+                hp[2 * pos + 1] = (float)(im / N);
             }
-            const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
-            const int pos = k2 * 256 + 16 * k0 + k1;
-            hp[2 * pos] = (float)(re / N);
-            hp[2 * pos + 1] = (float)(im / N);
         }
         if ((e = hipMalloc(&f->d_hperm, hp.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
         if ((e = hipMemcpy(f->d_hperm, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
@@ -261,7 +269,8 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.channels = (long long)f->channels;
         fa.halo = f->fft_halo;
         fa.hist_len = f->hist_len;
-        fa.interior_split = 0;
+        fa.parts = f->fft_parts;
+        fa.t_lo = fa.t_hi = 0;
         fa.ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
         SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur],

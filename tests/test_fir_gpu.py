@@ -53,6 +53,48 @@ CASES = [
 ]
 
 
+@pytest.fixture
+def force_path(monkeypatch):
+    """Select the kernel family regardless of the tap-count heuristic: the library
+    reads SDR_AMD_FFT when a state is created ("0" direct form, "1" overlap-save FFT)."""
+    def _set(path):
+        if path == "auto":
+            monkeypatch.delenv("SDR_AMD_FFT", raising=False)
+        else:
+            monkeypatch.setenv("SDR_AMD_FFT", "1" if path == "fft" else "0")
+    return _set
+
+
+@pytest.mark.parametrize("path", ["direct", "fft"])
+@pytest.mark.parametrize("kind,ntaps,cplx", [("lowpass", 127, True), ("lowpass", 127, False), ("hilbert", 127, False),
+                                             ("hilbert", 128, True), ("lowpass", 255, True), ("random", 16, False),
+                                             ("random", 2, True), ("lowpass", 1000, False), ("bandpass", 4095, True)])
+def test_both_kernel_families(force_path, path, kind, ntaps, cplx):
+    """Every tap count runs on both the direct-form and the overlap-save FFT kernels."""
+    force_path(path)
+    rng = np.random.default_rng(ntaps + 3 * cplx)
+    taps = taps_for(kind, ntaps)
+    n = 33333
+    x = rand(rng, n, cplx)
+    st = sdr_amd.FirState(taps, cplx)
+    assert ("fft" in st.kernel_name) == (path == "fft"), st.kernel_name
+    cuts = [0, 1, 4000, 4001, 12288, 20000, n]   # tile-sized, tiny and ragged calls
+    y = np.concatenate([sdr_amd.fir(st, x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+    assert rel_err(y, O.fir(taps, x)) <= TOL
+
+
+@pytest.mark.parametrize("ntaps", [2049, 2050, 4096, 9001])
+def test_partitioned_long_filters(ntaps):
+    """More than 2049 taps: uniformly partitioned overlap-save (hop 2048)."""
+    rng = np.random.default_rng(ntaps)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps)).astype(np.float32)
+    x = rand(rng, 40000, True)
+    st = sdr_amd.FirState(taps, True)
+    assert "fft" in st.kernel_name
+    y = np.concatenate([sdr_amd.fir(st, x[:17000]), sdr_amd.fir(st, x[17000:17001]), sdr_amd.fir(st, x[17001:])])
+    assert rel_err(y, O.fir(taps, x)) <= TOL
+
+
 @pytest.mark.parametrize("kind,ntaps,cplx", CASES)
 def test_single_call_vs_oracle(kind, ntaps, cplx):
     rng = np.random.default_rng(ntaps * 2 + cplx)
@@ -60,7 +102,7 @@ def test_single_call_vs_oracle(kind, ntaps, cplx):
     n = 20011  # ragged: not a multiple of any tile size
     x = rand(rng, n, cplx)
     st = sdr_amd.FirState(taps, cplx)
-    if kind == "hilbert" and 8 <= ntaps < 192:
+    if kind == "hilbert" and 8 <= ntaps < 100:
         assert st.tap_stride == 2, "short Hilbert taps must select the zero-skipping direct kernel"
     y = sdr_amd.fir(st, x)
     ref = O.fir(taps, x)
