@@ -102,6 +102,32 @@ int sdr_fir_tap_stride(const sdr_fir_t* f);
 /* Name of the HIP kernel a process call launches (for profiles). */
 const char* sdr_fir_kernel_name(const sdr_fir_t* f);
 
+/* Fused FIR chain ----------------------------------------------------------- */
+typedef struct sdr_chain sdr_chain_t;
+
+/* Replaces a pipeline of FIR blocks on one stream, e.g. `hilbert | stream-filter
+ * fir=lowpass` (reference: one kfr::fir per process, blocks/hilbert.cpp:72-86, chained
+ * through unix pipes): stage k filters with taps[k][0..ntaps[k]) and then drops its
+ * first skips[k] outputs (hilbert's group-delay compensation, blocks/hilbert.cpp:46,
+ * 75-86; 0 for a plain FIR).  The cascade is evaluated in ONE pass with the
+ * convolved taps (spectra multiply), so no intermediate stream touches HBM; the
+ * first sum_k>=2 (ntaps[k]-1-skips[k]) outputs, where the stage-by-stage result
+ * differs from the single filter (a dropped warm-up sample is not fed to the next
+ * stage), are computed stage by stage.  Results equal the staged pipeline within
+ * fp32 rounding. */
+int sdr_chain_create(sdr_chain_t** out, size_t nstages, const float* const* taps, const size_t* ntaps,
+                     const size_t* skips, int sample_kind, size_t channels, int device);
+/* n input samples per channel in DEVICE memory -> *n_out output samples per channel
+ * (n minus what the skips still swallow at the start of the stream), written from
+ * d_out[c*out_stride].  Stream position, histories and pending skips carry from
+ * call to call.  Asynchronous on hip_stream. */
+int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t in_stride, size_t n, void* d_out,
+                             size_t out_stride, size_t* n_out, void* hip_stream);
+int sdr_chain_reset(sdr_chain_t* c);
+void sdr_chain_destroy(sdr_chain_t* c);
+/* Taps of the single equivalent filter (for tests). */
+size_t sdr_chain_ntaps(const sdr_chain_t* c);
+
 /* Waveform generator ("gen" block producer, fused chains) ------------------ */
 enum { SDR_WAVE_COSINE = 0, SDR_WAVE_SINE = 1, SDR_WAVE_SQUARE = 2, SDR_WAVE_TRIANGLE = 3, SDR_WAVE_SAWTOOTH = 4 };
 typedef struct sdr_gen sdr_gen_t;

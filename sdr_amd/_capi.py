@@ -49,6 +49,21 @@ def lib():
         L.sdr_fir_tap_stride.argtypes = [vp]
         L.sdr_fir_kernel_name.argtypes = [vp]
         L.sdr_fir_kernel_name.restype = C.c_char_p
+        L.sdr_chain_create.argtypes = [C.POINTER(vp), sz, C.POINTER(fp), C.POINTER(sz), C.POINTER(sz), C.c_int, sz, C.c_int]
+        L.sdr_chain_process_device.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz), vp]
+        L.sdr_chain_reset.argtypes = [vp]
+        L.sdr_chain_destroy.argtypes = [vp]
+        L.sdr_chain_destroy.restype = None
+        L.sdr_chain_ntaps.argtypes = [vp]
+        L.sdr_chain_ntaps.restype = sz
+        L.sdr_gen_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, sz, C.c_int]
+        L.sdr_gen_set_frequency.argtypes = [vp, C.c_float]
+        L.sdr_gen_generate_device.argtypes = [vp, sz, vp, vp]
+        L.sdr_gen_generate.argtypes = [vp, sz, vp]
+        L.sdr_gen_destroy.argtypes = [vp]
+        L.sdr_gen_destroy.restype = None
+        L.sdr_optimal_block_size.argtypes = [C.c_uint64, C.c_uint64]
+        L.sdr_optimal_block_size.restype = sz
         L.sdr_host_alloc.argtypes = [sz]
         L.sdr_host_alloc.restype = vp
         L.sdr_host_free.argtypes = [vp]
@@ -210,3 +225,100 @@ def fir(state, x):
     if hasattr(x, "is_cuda"):
         return state.process_tensor(x)
     return state.process(x)
+
+
+class Chain:
+    """A cascade of FIR stages (each: taps, then drop `skip` leading outputs) run as one
+    pass on the GPU -- the fused form of `hilbert | stream-filter fir=...`."""
+
+    def __init__(self, stages, complex_samples=False, channels=1, device=0):
+        """stages: list of (taps, skip)."""
+        self.complex_samples = bool(complex_samples)
+        self.channels = int(channels)
+        taps = [np.ascontiguousarray(t, np.float32) for t, _ in stages]
+        self._keep = taps
+        n = len(stages)
+        tp = (C.POINTER(C.c_float) * n)(*[_fp(t) for t in taps])
+        nt = (C.c_size_t * n)(*[len(t) for t in taps])
+        sk = (C.c_size_t * n)(*[int(s) for _, s in stages])
+        self._h = C.c_void_p()
+        _check(lib().sdr_chain_create(C.byref(self._h), n, tp, nt, sk,
+                                      SDR_COMPLEX if self.complex_samples else SDR_REAL, self.channels, int(device)))
+
+    @property
+    def ntaps(self):
+        return lib().sdr_chain_ntaps(self._h)
+
+    def process_device(self, d_in, n, d_out, in_stride=None, out_stride=None, stream=None):
+        n_out = C.c_size_t(0)
+        _check(lib().sdr_chain_process_device(self._h, d_in, n if in_stride is None else in_stride, n, d_out,
+                                              n if out_stride is None else out_stride, C.byref(n_out),
+                                              C.c_void_p(stream or 0)))
+        return n_out.value
+
+    def process_tensor(self, x, out=None):
+        """x: (n,) / (channels, n) float32 [real] or (..., n, 2) [complex] CUDA tensor.
+        Returns (out, n_out): the first n_out samples of each channel row are valid."""
+        import torch
+        assert x.is_cuda and x.is_contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        n = x.shape[-2] if self.complex_samples else x.shape[-1]
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        n_out = self.process_device(x.data_ptr(), n, out.data_ptr(), stream=stream)
+        return out, n_out
+
+    def reset(self):
+        _check(lib().sdr_chain_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdr_chain_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+WAVEFORMS = {"cosine": 0, "sine": 1, "square": 2, "triangle": 3, "sawtooth": 4}
+
+
+class Gen:
+    """The reference `gen` block's sample synthesis on the GPU (sdr_gen_*)."""
+
+    def __init__(self, waveform, complex_samples, amp, cycles_per_sample, phase_degrees, block_size, device=0):
+        self.complex_samples = bool(complex_samples)
+        self.block_size = int(block_size)
+        self._h = C.c_void_p()
+        _check(lib().sdr_gen_create(C.byref(self._h), WAVEFORMS[waveform],
+                                    SDR_COMPLEX if self.complex_samples else SDR_REAL, amp, cycles_per_sample,
+                                    phase_degrees, self.block_size, int(device)))
+
+    def generate(self, blocks):
+        out = np.empty(blocks * self.block_size, np.complex64 if self.complex_samples else np.float32)
+        _check(lib().sdr_gen_generate(self._h, blocks, out.ctypes.data))
+        return out
+
+    def generate_device(self, blocks, d_out, stream=None):
+        _check(lib().sdr_gen_generate_device(self._h, blocks, d_out, C.c_void_p(stream or 0)))
+
+    def set_frequency(self, cps):
+        _check(lib().sdr_gen_set_frequency(self._h, cps))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sdr_gen_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def optimal_block_size(element_size, sample_rate=0):
+    return lib().sdr_optimal_block_size(element_size, sample_rate)

@@ -13,8 +13,11 @@
 //            (no fract: the fp32 rounding of the angle is part of the result).
 // phi_k follows the sequential fp32 recurrence phi_{k+1} = fract(phi_k + fract(cps*B));
 // it is computed on the host and passed as a table.
-// __fmul_rn/__fadd_rn keep hipcc from contracting a*b+c into an FMA.
+// The reference build has no fused multiply-add: this file is compiled with
+// -ffp-contract=off (Makefile) and repeats it here, because HIP's __fmul_rn/__fadd_rn
+// are plain operators that the compiler would otherwise still contract into v_fma_f32.
 #include <hip/hip_runtime.h>
+#pragma clang fp contract(off)
 
 #include "gen_kernels.h"
 

@@ -1,0 +1,143 @@
+"""GPU tests of the fused chain (sdr_chain_*) and the device generator (sdr_gen_*):
+BASELINE configs 4 and 5 in small -- hilbert (127 taps, group-delay skip) followed by
+a 127-tap lowpass, per channel, as one pass -- against the ORACLE evaluated stage by
+stage exactly like a `hilbert | stream-filter` pipeline of reference blocks would."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import sdr_amd
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel_err(a, b):
+    a = np.asarray(a).astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+    b = np.asarray(b).astype(np.complex128 if np.iscomplexobj(b) else np.float64)
+    return float(np.max(np.abs(a - b)) / np.sqrt(np.mean(np.abs(b) ** 2)))
+
+
+def staged_oracle(stages, x):
+    """Stage by stage: FIR, then drop the first `skip` outputs (blocks/hilbert.cpp:75-86)."""
+    y = x
+    for taps, skip in stages:
+        y = O.fir(taps, y)[skip:]
+    return y
+
+
+def run_chain(chain, x, cuts, cplx):
+    import torch
+    outs, p = [], 0
+    for c in cuts:
+        part = x[p:p + c]
+        p += c
+        if c == 0:
+            continue
+        h = part.view(np.float32).reshape(-1, 2) if cplx else part
+        d = torch.from_numpy(np.ascontiguousarray(h)).cuda()
+        out, n_out = chain.process_tensor(d)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        o = o.reshape(-1).view(np.complex64) if cplx else o
+        outs.append(o[:n_out])
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("cuts", [[30000], [10, 53, 1, 100, 25, 400, 29411], [63, 126, 189, 29622]])
+def test_hilbert_then_lowpass_equals_staged_pipeline(cplx, cuts):
+    rng = np.random.default_rng(17)
+    n = sum(cuts)
+    x = rng.uniform(-1, 1, n * (2 if cplx else 1)).astype(np.float32)
+    x = x.view(np.complex64) if cplx else x
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.1), 0)]
+    chain = sdr_amd.Chain(stages, cplx)
+    assert chain.ntaps == 253
+    got = run_chain(chain, x, cuts, cplx)
+    ref = staged_oracle(stages, x)
+    assert got.shape == ref.shape          # N - 63 outputs: no sample dropped or duplicated
+    assert rel_err(got, ref) <= TOL
+    # the warm-up region is where a single 253-tap filter would be wrong
+    assert rel_err(got[:200], ref[:200]) <= TOL
+
+
+def test_three_stage_chain_with_two_skips():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, 20000).astype(np.float32)
+    stages = [(sdr_amd.hilbert(31), 15), (sdr_amd.fir_lowpass(63, 0.2), 31), (sdr_amd.fir_bandpass(255, 0.05, 0.2), 0)]
+    chain = sdr_amd.Chain(stages, False)
+    got = run_chain(chain, x, [5, 40, 3, 700, 19252], False)
+    ref = staged_oracle(stages, x)
+    assert got.shape == ref.shape and rel_err(got, ref) <= TOL
+    chain.reset()
+    got2 = run_chain(chain, x[:5000], [5000], False)
+    assert rel_err(got2, ref[:len(got2)]) <= TOL
+
+
+def test_multichannel_chain_config4_small():
+    """Config C4 in small: independent channels, sines at f_c = (c+1)/160, hilbert then
+    lowpass, channels laid out [channel][sample]."""
+    import torch
+    C, n = 8, 12000
+    t = np.arange(n)
+    x = np.stack([np.sin(2 * np.pi * (c + 1) / 160.0 * t) for c in range(C)]).astype(np.float32)
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.1), 0)]
+    chain = sdr_amd.Chain(stages, False, channels=C)
+    d = torch.from_numpy(x).cuda()
+    out, n_out = chain.process_tensor(d)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()[:, :n_out]
+    assert n_out == n - 63
+    for c in range(C):
+        ref = staged_oracle(stages, x[c])
+        assert np.max(np.abs(got[c] - ref)) <= TOL * np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+
+
+def test_gen_device_matches_oracle_recipe():
+    """sdr_gen_*: bit-level restatement of the reference generator (polynomial sine,
+    per-block fp32 phase recurrence) -- compared with the oracle's restatement, which
+    is itself pinned to the reference's packets (tests/test_oracle_golden.py)."""
+    B = sdr_amd.optimal_block_size(4, 1000000)
+    assert B == 2044
+    cps = float(np.float32(100e3) / np.float32(1e6))
+    for wf, code in (("sine", 1), ("cosine", 0)):
+        g = sdr_amd.Gen(wf, False, 0.75, cps, 30.0, B)
+        a = np.concatenate([g.generate(3), g.generate(70)])   # phase carries across calls
+        phi0 = np.float32(30.0) / np.float32(360.0)
+        ref, _ = O.gen_real(73, B, 0.75, cps, float(phi0), code)
+        d = np.abs(a - ref)
+        assert d.max() == 0.0, (wf, float(d.max()), int(np.count_nonzero(d)), int(np.argmax(d)))  # same fp32 recipe, no FMA: bit-exact
+    Bc = sdr_amd.optimal_block_size(8, 1000000)
+    g = sdr_amd.Gen("sine", True, 0.5, cps, 0.0, Bc)
+    a = g.generate(5)
+    ref, _ = O.gen_complex(5, Bc, 0.5, cps, 0.0, 1)
+    assert np.max(np.abs(a - ref)) <= 3e-7
+
+
+def test_fused_gen_chain_config5_small():
+    """Config C5 in small: generator -> hilbert(127, delay skip) -> lowpass(127) with the
+    generated samples never leaving the GPU, chunk by chunk; compared with the oracle's
+    generator + staged filters."""
+    import torch
+    B = 2044
+    cps = float(np.float32(100e3) / np.float32(1e6))
+    blocks, per_call = 24, 5
+    gen = sdr_amd.Gen("sine", False, 1.0, cps, 0.0, B)
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.12), 0)]
+    chain = sdr_amd.Chain(stages, False)
+    buf = torch.empty(per_call * B, dtype=torch.float32, device="cuda")
+    outs = []
+    done = 0
+    stream = torch.cuda.current_stream().cuda_stream
+    while done < blocks:
+        nb = min(per_call, blocks - done)
+        gen.generate_device(nb, buf.data_ptr(), stream=stream)
+        out, n_out = chain.process_tensor(buf[: nb * B])
+        torch.cuda.synchronize()
+        outs.append(out[:n_out].cpu().numpy())
+        done += nb
+    got = np.concatenate(outs)
+    x, _ = O.gen_real(blocks, B, 1.0, cps, 0.0, 1)
+    ref = staged_oracle(stages, x)
+    assert got.shape == ref.shape and rel_err(got, ref) <= TOL
