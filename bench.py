@@ -46,7 +46,48 @@ WORKLOADS = {
     "c4": ("64 channels x 2^22 real samples, hilbert 127 taps (BASELINE configs[3] first stage)",
            False, lambda S: S.hilbert(127), 22, 64),
     "lp255": ("255-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(255, 0.1), 28, 1),
+    # fused chains (sdr_chain_*): handled by bench_chain() below
+    "c4chain": ("64 channels x 2^22 real samples, hilbert(127, delay skip) + lowpass(127) fused in one pass "
+                "(BASELINE configs[3])", False, None, 22, 64),
+    "c5": ("fused gen(sine) -> hilbert(127) -> lowpass(127): 2^29 real outputs per GPU, generated on device in "
+           "2^24-sample chunks that never leave the GPU (BASELINE configs[4], per-GPU share)", False, None, 29, 1),
 }
+
+
+def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
+    """c4chain / c5: per step, every rank pushes its share through the fused chain."""
+    desc, cplx, _, log2n, channels = WORKLOADS[args.workload]
+    n = 1 << log2n
+    stages = [(S.hilbert(127), 63), (S.fir_lowpass(127, 0.1), 0)]
+    chain = S.Chain(stages, False, channels=channels, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    if args.workload == "c4chain":
+        # channel c of the global set: sine at f = (c+1)/160 cycles/sample (SURVEY 8d C4)
+        t = torch.arange(n, device=dev, dtype=torch.float32)
+        x = torch.stack([torch.sin(2 * np.pi * ((rank * channels + c) % 64 + 1) / 160.0 * t) for c in range(channels)])
+        y = torch.empty_like(x)
+
+        def step():
+            chain.process_tensor(x, y)
+        bytes_per_step = n * channels * 8
+        units = n * channels
+    else:
+        B = S.optimal_block_size(4, 1000000)
+        blocks_per_chunk = (1 << args.chunk_log2) // B
+        chunk = blocks_per_chunk * B
+        nchunks = n // chunk
+        gen = S.Gen("sine", False, 1.0, float(np.float32(100e3) / np.float32(1e6)), 0.0, B, device=local_rank)
+        buf = torch.empty(chunk, dtype=torch.float32, device=dev)
+        y = torch.empty(nchunks * chunk, dtype=torch.float32, device=dev)
+
+        def step():
+            for i in range(nchunks):
+                gen.generate_device(blocks_per_chunk, buf.data_ptr(), stream=stream)
+                chain.process_device(buf.data_ptr(), chunk, y.data_ptr() + 4 * i * chunk, stream=stream)
+        bytes_per_step = nchunks * chunk * 4
+        units = nchunks * chunk
+    return step, units, bytes_per_step, "sdr_chain(253 fused taps) -> " + "fir_fft4096_interior<REAL>", 253, desc
+
 
 
 def fill_counter_based(x, first_sample, seed=0x5D12):
@@ -108,6 +149,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=27)
+    ap.add_argument("--chunk-log2", type=int, default=26, help="c5: samples per generated chunk")
     args = ap.parse_args()
 
     import torch
@@ -128,6 +170,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     desc, cplx, mk_taps, log2n, channels = WORKLOADS[args.workload]
+    if mk_taps is None:
+        step, units, step_bytes, kernel_name, ntaps, desc = bench_chain(args, S, torch, dist, rank, local_rank, world, dev)
+        run_and_report(args, torch, dist, rank, world, dev, step, units, step_bytes, kernel_name, ntaps, desc,
+                       "float32", channels, None)
+        return
     taps = mk_taps(S)
     n = 1 << log2n
     w = 2 if cplx else 1
@@ -154,8 +201,17 @@ def main():
     if cplx and channels > 1:
         xin, yout = x.view(channels, n, 2), y.view(channels, n, 2)
 
+    def step():
+        st.process_tensor(xin, yout)  # launches on torch's current stream
+    run_and_report(args, torch, dist, rank, world, dev, step, n * channels, n * channels * 8 * w, st.kernel_name,
+                   int(len(taps)), desc, "complex64" if cplx else "float32", channels, (taps, cplx, log2n))
+
+
+def run_and_report(args, torch, dist, rank, world, dev, step, units, step_bytes, kernel_name, ntaps, desc, kind,
+                   channels, cpu_spec):
+    """W warm-up steps, K timed steps between barrier + synchronize, max over ranks, one JSON line."""
     for _ in range(args.warmup):
-        st.process_tensor(xin, yout)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -164,7 +220,7 @@ def main():
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
-        st.process_tensor(xin, yout)  # launches on torch's current stream
+        step()
         ev[i + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -174,38 +230,37 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # per-launch device time of the FIR kernel (+ its 2 us history-carry kernel),
-    # HIP events on the launch stream
+    # device time per step: HIP events on the launch stream (torch's current stream is
+    # the stream every kernel of the step is launched on)
     kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     kern_ms_avg = float(np.mean(kern_ms))
 
     if rank == 0:
-        samples_per_step = n * channels * world
-        value = samples_per_step * args.steps / elapsed / 1e6
-        bytes_per_sample = 8 * w  # 4*w read + 4*w written
-        achieved = n * channels * bytes_per_sample / (kern_ms_avg * 1e-3) / 1e9
-        flops = 2.0 * w * len(taps) * n * channels  # dense nominal
+        value = units * world * args.steps / elapsed / 1e6
+        achieved = step_bytes / (kern_ms_avg * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s (FIR hot path: %s)" % args.workload,
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "samples_per_gpu": n * channels, "channels": channels,
-                       "taps": int(len(taps)), "sample_kind": "complex64" if cplx else "float32",
-                       "kernel": st.kernel_name, "sharding": "contiguous chunks with regenerated halo, no collective"},
+            "config": {"workload": desc, "samples_per_gpu": units, "channels": channels,
+                       "taps": ntaps, "sample_kind": kind, "kernel": kernel_name,
+                       "sharding": "contiguous chunks with regenerated halo / channel groups, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": kern_ms_avg, "kernel_ms_min": float(np.min(kern_ms)),
-                         "algorithmic_bytes_per_launch": n * channels * bytes_per_sample,
-                         "valu_tflops_dense_nominal": flops / (kern_ms_avg * 1e-3) / 1e12,
-                         "valu_frac_of_157.3": flops / (kern_ms_avg * 1e-3) / 157.3e12},
+                         "algorithmic_bytes_per_launch": step_bytes,
+                         # what a direct-form evaluation of the same outputs would need
+                         # (2*taps flop per real MAC lane); the FFT path does ~4x fewer flops
+                         "direct_form_equivalent_tflops": 2.0 * ntaps * units * (2 if kind == "complex64" else 1) / (kern_ms_avg * 1e-3) / 1e12},
         }
         tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tj):
             with open(tj) as f:
                 out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and cpu_spec is not None:
+            taps, cplx, log2n = cpu_spec
             out["cpu_baseline"] = cpu_baseline(taps, cplx, min(args.cpu_log2n, log2n))
         else:
             out["cpu_baseline"] = None

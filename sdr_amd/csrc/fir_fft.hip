@@ -129,13 +129,28 @@ __device__ __forceinline__ f2 unit_root(int m, int M) { // exp(-2 pi i m / M)
 // Per-lane constants, computed once per (persistent) workgroup and kept in VGPRs:
 //   TA[k] = W_4096^(tid k), TB[k] = W_256^((tid&15) k), H[k2] = spectrum/N of bin
 //   (tid>>4) + 16 (tid&15) + 256 k2.
-struct LaneConsts {
-    f2 TA[16], TB[16], H[16];
-    __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum) {
+// TBL: the W_256 twiddles are read from a 256-entry LDS table instead of 30 VGPRs.
+template <bool TBL>
+struct LaneConstsT {
+    f2 TA[16], TB[TBL ? 1 : 16], H[16];
+    const f2* tb_lds;
+    __device__ __forceinline__ f2 tb(int k) const {
+        if constexpr (TBL) return tb_lds[16 * k];
+        else return TB[k];
+    }
+    __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum, f2* table = nullptr) {
+        tb_lds = nullptr;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            TA[k] = unit_root((tid * k) & 4095, 4096);
-            TB[k] = unit_root(((tid & 15) * k) & 255, 256);
+        for (int k = 1; k < 16; ++k) TA[k] = unit_root((tid * k) & 4095, 4096);
+        if constexpr (TBL) {
+            // table[16 k + n] = W_256^(n k); a lane reads column n = tid & 15 (broadcast within 16-lane groups)
+            table[tid] = unit_root(((tid & 15) * (tid >> 4)) & 255, 256);
+            tb_lds = table + (tid & 15);
+            __syncthreads();
+        } else {
+            (void)table;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) TB[k] = unit_root(((tid & 15) * k) & 255, 256);
         }
         if (with_spectrum) {
 #pragma unroll
@@ -147,8 +162,8 @@ struct LaneConsts {
 // Forward transform of one tile: v[n2] = x[256 n2 + tid] in, X[(tid>>4) + 16 (tid&15)
 // + 256 k2] left at v[P16(k2)].  `after_points_left` runs once the input points have
 // left the registers (the slot where the next tile's loads are issued).
-template <class Hook>
-__device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const LaneConsts& c, Hook&& after_points_left) {
+template <class Consts, class Hook>
+__device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const Consts& c, Hook&& after_points_left) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
     // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
@@ -165,7 +180,7 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
     dft16<false>(v);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.TB[k]);
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.tb(k));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
@@ -178,7 +193,8 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
 
 // Inverse transform: w[k2] = Y[(tid>>4) + 16 (tid&15) + 256 k2] in (natural k2 order),
 // y[256 n2 + tid] left at w[P16(n2)].
-__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const LaneConsts& c) {
+template <class Consts>
+__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const Consts& c) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW;
     // ---- C': over k2 -> n0 --------------------------------------------------------
@@ -191,7 +207,7 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = row1[k * 17 + l16];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.TB[k]);
+    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.tb(k));
     dft16<true>(w);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -220,13 +236,13 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // LONG = uniformly partitioned overlap-save for more than 2049 taps: hop L = 2048,
 // the filter is cut into `parts` pieces of 2048 taps, Y_b = sum_p X_(b-p) H_p; the
 // windows b-1.. are re-read (L2) and re-transformed, spectra H_p come from L2.
-template <bool REAL, int HB, bool LONG>
-__global__ __launch_bounds__(256, 2) void fir_fft4096_interior(FftArgs a) {
+template <bool REAL, int HB, bool LONG, bool TBL>
+__global__ __launch_bounds__(256, TBL ? 3 : 2) void fir_fft4096_interior(FftArgs a) {
     static_assert(!LONG || HB == 8, "partitioned mode uses hop 2048");
-    __shared__ __align__(16) f2 lds[16 * ROW];
+    __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     const int tid = threadIdx.x;
-    LaneConsts c;
-    c.init(tid, a.hperm, !LONG);
+    LaneConstsT<TBL> c;
+    c.init(tid, a.hperm, !LONG, TBL ? lds + 16 * ROW : nullptr);
     constexpr int W = REAL ? 1 : 2;
     constexpr long long L = FFT_N - 256 * HB;
     constexpr long long per_tile = REAL ? 2 * L : L;
@@ -321,7 +337,7 @@ template <bool REAL>
 __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * ROW];
     const int tid = threadIdx.x;
-    LaneConsts c;
+    LaneConstsT<false> c;
     c.init(tid, a.hperm, false);
     constexpr int W = REAL ? 1 : 2;
     const int halo = a.halo;
@@ -382,14 +398,16 @@ template <bool REAL>
 static hipError_t launch_interior(const FftArgs& a, long long grid, hipStream_t stream) {
     const dim3 g((unsigned)grid), b(256);
     if (a.parts > 1) {
-        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true>), g, b, 0, stream, a);
+        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, false>), g, b, 0, stream, a);
         return hipGetLastError();
     }
+    // W_256 twiddles from the LDS table: 161 VGPRs, three workgroups per CU (+3 % over
+    // the all-register build at two per CU, profiles/r01_fft_variants.txt)
     switch (a.halo / 256) {
-        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false>), g, b, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false>), g, b, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false, true>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false, true>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false, true>), g, b, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false, true>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -52,14 +52,15 @@ __device__ __forceinline__ float wave_real(int waveform, float arg) {
     }
 }
 
+// grid.x = packet (block) index, grid.y * 256 lanes cover the in-block index: no
+// division on the per-sample path, coalesced 4/8-byte stores.
 __global__ __launch_bounds__(256) void gen_blocks(GenArgs a) {
-    const long long total = (long long)a.blocks * a.block_size;
-    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < total;
-         s += (long long)gridDim.x * blockDim.x) {
-        const long long b = s / a.block_size;
-        const int i = (int)(s - b * a.block_size);
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= a.block_size) return;
+    for (long long b = blockIdx.x; b < a.blocks; b += gridDim.x) {
         const float phi = a.phi[b];
         const float step = __fmul_rn(a.cps, (float)i);
+        const long long s = b * a.block_size + i;
         if (!a.complex_samples) {
             const float base = a.waveform == 0 ? __fadd_rn(phi, 0.25f) : phi;
             a.out[s] = __fmul_rn(a.amp, wave_real(a.waveform, __fadd_rn(base, step)));
@@ -74,11 +75,11 @@ __global__ __launch_bounds__(256) void gen_blocks(GenArgs a) {
 }
 
 hipError_t launch_gen(const GenArgs& a, hipStream_t stream) {
-    const long long total = (long long)a.blocks * a.block_size;
-    if (total == 0) return hipSuccess;
-    long long grid = (total + 255) / 256;
-    if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(gen_blocks, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    if (a.blocks == 0 || a.block_size == 0) return hipSuccess;
+    const unsigned gy = (unsigned)((a.block_size + 255) / 256);
+    if (gy > 65535) return hipErrorInvalidValue;
+    const long long gx = a.blocks < 2048 ? a.blocks : 2048; // each workgroup walks over many packets
+    hipLaunchKernelGGL(gen_blocks, dim3((unsigned)gx, gy), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -221,7 +221,7 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
             return bail(e, "hipMemcpy(spectrum)");
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", 2);
+        f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 6);
     }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
@@ -411,10 +411,16 @@ struct sdr_gen {
     float amp = 1.0f, cps = 0.0f, phi = 0.0f, phi_incr = 0.0f;
     size_t block_size = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t table_free = nullptr; // the phase table may be overwritten after this
-    float* h_phi = nullptr;          // pinned
-    float* d_phi = nullptr;
-    size_t phi_cap = 0;
+    // ring of per-call phase tables (pinned host + device copy): the host fills table
+    // k+1 while the GPU still reads table k, so back-to-back calls never stall
+    static constexpr int kRing = 4;
+    struct Table {
+        hipEvent_t free = nullptr; // recorded after the kernel that reads the table
+        float* h = nullptr;        // pinned
+        float* d = nullptr;
+        size_t cap = 0;
+    } table[kRing];
+    int next_table = 0;
     float* d_out = nullptr; // staging for the host entry point
     size_t out_cap = 0;
 };
@@ -460,8 +466,10 @@ extern "C" int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, fl
     g->block_size = block_size;
     DeviceGuard guard(device);
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&g->table_free, hipEventDisableTiming)) != hipSuccess) {
+    e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    for (auto& t : g->table)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&t.free, hipEventDisableTiming);
+    if (e != hipSuccess) {
         int rc = hip_fail(e, "sdr_gen_create");
         std::string keep = g_last_error;
         sdr_gen_destroy(g);
@@ -482,30 +490,30 @@ extern "C" int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample) {
 
 static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
     if (blocks == 0) return SDR_OK;
-    if (blocks > g->phi_cap) {
-        SDR_HIP(hipEventSynchronize(g->table_free));
-        if (g->h_phi) (void)hipHostFree(g->h_phi);
-        if (g->d_phi) (void)hipFree(g->d_phi);
-        g->h_phi = g->d_phi = nullptr;
-        g->phi_cap = 0;
+    sdr_gen::Table& t = g->table[g->next_table];
+    g->next_table = (g->next_table + 1) % sdr_gen::kRing;
+    SDR_HIP(hipEventSynchronize(t.free)); // the call that used this slot 4 calls ago
+    if (blocks > t.cap) {
+        if (t.h) (void)hipHostFree(t.h);
+        if (t.d) (void)hipFree(t.d);
+        t.h = t.d = nullptr;
+        t.cap = 0;
         const size_t cap = std::max<size_t>(blocks, 4096);
-        SDR_HIP(hipHostMalloc(&g->h_phi, cap * sizeof(float), hipHostMallocDefault));
-        SDR_HIP(hipMalloc(&g->d_phi, cap * sizeof(float)));
-        g->phi_cap = cap;
-    } else {
-        SDR_HIP(hipEventSynchronize(g->table_free)); // previous table still in use?
+        SDR_HIP(hipHostMalloc(&t.h, cap * sizeof(float), hipHostMallocDefault));
+        SDR_HIP(hipMalloc(&t.d, cap * sizeof(float)));
+        t.cap = cap;
     }
     // sequential fp32 phase recurrence, one value per block (gen.cpp:185,192,227)
     float phi = g->phi;
     for (size_t b = 0; b < blocks; ++b) {
-        g->h_phi[b] = phi;
+        t.h[b] = phi;
         phi = fractf_host(phi + g->phi_incr);
     }
     g->phi = phi;
-    SDR_HIP(hipMemcpyAsync(g->d_phi, g->h_phi, blocks * sizeof(float), hipMemcpyHostToDevice, stream));
+    SDR_HIP(hipMemcpyAsync(t.d, t.h, blocks * sizeof(float), hipMemcpyHostToDevice, stream));
     GenArgs a;
     a.out = d_out;
-    a.phi = g->d_phi;
+    a.phi = t.d;
     a.blocks = (long long)blocks;
     a.block_size = (long long)g->block_size;
     a.amp = g->amp;
@@ -513,7 +521,7 @@ static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t 
     a.waveform = g->waveform;
     a.complex_samples = g->kind == SDR_COMPLEX;
     SDR_HIP(launch_gen(a, stream));
-    SDR_HIP(hipEventRecord(g->table_free, stream));
+    SDR_HIP(hipEventRecord(t.free, stream));
     return SDR_OK;
 }
 
@@ -553,10 +561,12 @@ extern "C" void sdr_gen_destroy(sdr_gen_t* g) {
     if (!g) return;
     DeviceGuard guard(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
-    if (g->h_phi) (void)hipHostFree(g->h_phi);
-    if (g->d_phi) (void)hipFree(g->d_phi);
+    for (auto& t : g->table) {
+        if (t.h) (void)hipHostFree(t.h);
+        if (t.d) (void)hipFree(t.d);
+        if (t.free) (void)hipEventDestroy(t.free);
+    }
     if (g->d_out) (void)hipFree(g->d_out);
-    if (g->table_free) (void)hipEventDestroy(g->table_free);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
