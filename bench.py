@@ -41,8 +41,10 @@ WORKLOADS = {
     "c1big": ("hilbert 127 taps on 2^28 real float32 samples, in-memory", False, lambda S: S.hilbert(127), 28, 1),
     "c2real": ("127-tap lowpass on 2^28 real float32 samples, in-memory", False, lambda S: S.fir_lowpass(127, 0.1), 28, 1),
     "hilbc": ("hilbert 127 taps on 2^28 complex samples, in-memory", True, lambda S: S.hilbert(127), 28, 1),
-    "c3": ("stream_filter 4095-tap bandpass on 2^26 complex samples (direct form), in-memory (BASELINE configs[2])",
-           True, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 26, 1),
+    "c3": ("stream_filter 4095-tap bandpass on 2^26 complex samples (partitioned overlap-save), in-memory "
+           "(BASELINE configs[2])", True, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 26, 1),
+    "c3real": ("4095-tap bandpass on 2^27 real samples (partitioned overlap-save), in-memory",
+               False, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 27, 1),
     "c4": ("64 channels x 2^22 real samples, hilbert 127 taps (BASELINE configs[3] first stage)",
            False, lambda S: S.hilbert(127), 22, 64),
     "lp255": ("255-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(255, 0.1), 28, 1),

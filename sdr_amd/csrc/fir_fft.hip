@@ -236,9 +236,14 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // LONG = uniformly partitioned overlap-save for more than 2049 taps: hop L = 2048,
 // the filter is cut into `parts` pieces of 2048 taps, Y_b = sum_p X_(b-p) H_p; the
 // windows b-1.. are re-read (L2) and re-transformed, spectra H_p come from L2.
-template <bool REAL, int HB, bool LONG, bool TBL>
-__global__ __launch_bounds__(256, TBL ? 3 : 2) void fir_fft4096_interior(FftArgs a) {
+// CACHE (LONG with exactly two partitions, 2050..4096 taps): every workgroup walks a
+// contiguous run of tiles and keeps X_(b-1) -- the spectrum it computed for the
+// previous tile -- in registers, so a tile costs one forward and one inverse
+// transform instead of two forward and one inverse.
+template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE>
+__global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_interior(FftArgs a) {
     static_assert(!LONG || HB == 8, "partitioned mode uses hop 2048");
+    static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     const int tid = threadIdx.x;
     LaneConstsT<TBL> c;
@@ -253,19 +258,29 @@ __global__ __launch_bounds__(256, TBL ? 3 : 2) void fir_fft4096_interior(FftArgs
     // 64-bit divisions; tt counts tiles of the channel from a.t_lo
     struct Pos { long long ch, tt; };
     auto advance = [&](Pos p) {
-        p.tt += gridDim.x;
+        p.tt += CACHE ? 1 : gridDim.x;
         while (p.tt >= a.t_hi) { p.tt -= inner; ++p.ch; }
         return p;
     };
+    // Real signals ride in pairs (re, im) = (x[o + m], x[o + D + m]).  Normally the pair is
+    // the two halves of one 2L-sample tile (D = L).  With the spectrum cache both members
+    // must advance by one hop per tile so that the previous tile's spectrum IS X_(b-1):
+    // the re member walks the first half of the channel's interior, the im member the
+    // second half (D = inner * L), one hop of L samples per tile each.
+    const long long D = (REAL && CACHE) ? inner * L : L;
+    auto first_out = [&](Pos p) -> long long {            // first output sample of the tile's re member
+        if (REAL && CACHE) return a.t_lo * per_tile + (p.tt - a.t_lo) * L;
+        return p.tt * per_tile;
+    };
     auto in_ptr = [&](Pos p) -> const float* {            // wave-uniform pointer to x[s0]
-        return a.in + (p.ch * a.in_stride + p.tt * per_tile - 256 * HB) * W;
+        return a.in + (p.ch * a.in_stride + first_out(p) - 256 * HB) * W;
     };
     auto load = [&](const float* p0, f2 (&dst)[16]) {
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             if (REAL) {
                 const float* q = p0 + 256 * n2;
-                dst[n2] = f2{__builtin_nontemporal_load(q + tid), __builtin_nontemporal_load(q + L + tid)};
+                dst[n2] = f2{__builtin_nontemporal_load(q + tid), __builtin_nontemporal_load(q + D + tid)};
             } else {
                 dst[n2] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
             }
@@ -274,18 +289,38 @@ __global__ __launch_bounds__(256, TBL ? 3 : 2) void fir_fft4096_interior(FftArgs
 
     if (inner <= 0 || (long long)blockIdx.x >= total) return;
     Pos cur{0, 0};
-    cur.tt = a.t_lo + blockIdx.x;
-    while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
+    long long left = 0;    // CACHE: tiles of this workgroup's run still to do
+    long long prev_ch = -1; // CACHE: channel whose X_(b-1) sits in `prev`
+    f2 prev[CACHE ? 16 : 1];
+    if (CACHE) {
+        const long long run = (total + gridDim.x - 1) / gridDim.x;
+        const long long first = (long long)blockIdx.x * run;
+        if (first >= total) return;
+        left = total - first < run ? total - first : run;
+        cur.ch = first / inner;
+        cur.tt = a.t_lo + (first - cur.ch * inner);
+    } else {
+        cur.tt = a.t_lo + blockIdx.x;
+        while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
+    }
     f2 nx[16];
     load(in_ptr(cur), nx);
 
     auto body = [&]() {
         f2 v[16];
+        if (CACHE && prev_ch != cur.ch) {
+            // start of a run or of a channel: transform window b-1 once
+            load(in_ptr(cur) - 2048 * W, v);
+            forward_tile(v, lds, tid, c, [] {});
+#pragma unroll
+            for (int k = 0; k < 16; ++k) prev[CACHE ? k : 0] = v[P16(k)];
+            prev_ch = cur.ch;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = nx[i];
         // past the end the workgroup re-loads its own tile (harmless): keeps the body branch-free
         Pos nxt = advance(cur);
-        if (nxt.ch >= a.channels) nxt = cur;
+        if (CACHE ? left <= 1 : nxt.ch >= a.channels) nxt = cur;
         const float* pn = in_ptr(nxt);
         f2 w[16];
         if (a.ablate & 1) {
@@ -296,7 +331,13 @@ __global__ __launch_bounds__(256, TBL ? 3 : 2) void fir_fft4096_interior(FftArgs
             forward_tile(v, lds, tid, c, [&] { load(pn, nx); });
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
-            if (LONG) {
+            if (CACHE) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    w[k] += cmul(prev[CACHE ? k : 0], spectrum(a.hperm, 1, k, tid));
+                    prev[CACHE ? k : 0] = v[P16(k)];
+                }
+            } else if (LONG) {
                 for (int p = 1; p < a.parts; ++p) {
                     load(in_ptr(cur) - (long long)p * 2048 * W, v); // window b-p (L2 resident)
                     forward_tile(v, lds, tid, c, [] {});
@@ -309,25 +350,26 @@ __global__ __launch_bounds__(256, TBL ? 3 : 2) void fir_fft4096_interior(FftArgs
             }
             inverse_tile(w, lds, tid, c);
         }
-        float* q0 = a.out + (cur.ch * a.out_stride + cur.tt * per_tile - 256 * HB) * W; // &y[-halo] of the tile
+        float* q0 = a.out + (cur.ch * a.out_stride + first_out(cur) - 256 * HB) * W; // &y[-halo] of the tile
 #pragma unroll
         for (int n2 = HB; n2 < 16; ++n2) {
             const f2 y = w[P16(n2)];
             if (REAL) {
                 float* q = q0 + 256 * n2;
                 __builtin_nontemporal_store(y.x, q + tid);
-                __builtin_nontemporal_store(y.y, q + L + tid);
+                __builtin_nontemporal_store(y.y, q + D + tid);
             } else {
                 __builtin_nontemporal_store(y, reinterpret_cast<f2*>(q0 + 512 * n2) + tid);
             }
         }
         cur = advance(cur);
+        --left;
     };
     // First tile peeled so that the loop header sees the same queue of outstanding
     // memory operations from both of its predecessors (16 loads, then this tile's
     // stores): the waits at the top of the loop then cover the loads only.
     body();
-    while (cur.ch < a.channels) body();
+    while (CACHE ? left > 0 : cur.ch < a.channels) body();
 }
 
 // ---- edge tiles: the first tile(s) of every channel (they read the carried history)
@@ -397,17 +439,21 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
 template <bool REAL>
 static hipError_t launch_interior(const FftArgs& a, long long grid, hipStream_t stream) {
     const dim3 g((unsigned)grid), b(256);
+    if (a.parts == 2 && !(a.ablate & 4)) {
+        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, true, true>), g, b, 0, stream, a);
+        return hipGetLastError();
+    }
     if (a.parts > 1) {
-        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, false>), g, b, 0, stream, a);
+        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, false, false>), g, b, 0, stream, a);
         return hipGetLastError();
     }
     // W_256 twiddles from the LDS table: 161 VGPRs, three workgroups per CU (+3 % over
     // the all-register build at two per CU, profiles/r01_fft_variants.txt)
     switch (a.halo / 256) {
-        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false, true>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false, true>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false, true>), g, b, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false, true>), g, b, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false, true, false>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false, true, false>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false, true, false>), g, b, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false, true, false>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -437,7 +483,11 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     if (inner == 0) a.t_lo = a.t_hi = 0;
     hipError_t e = hipSuccess;
     if (inner > 0) {
-        long long grid = inner * a.channels < grid_blocks ? inner * a.channels : grid_blocks;
+        // equal shares: with T tiles and at most G workgroups every workgroup walks
+        // ceil(T/G) tiles (or one fewer), instead of G workgroups of uneven load
+        const long long total = inner * a.channels;
+        const long long rounds = (total + grid_blocks - 1) / grid_blocks;
+        const long long grid = (total + rounds - 1) / rounds;
         e = real ? launch_interior<true>(a, grid, stream) : launch_interior<false>(a, grid, stream);
         if (e != hipSuccess) return e;
     }

@@ -222,6 +222,8 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 6);
+        // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
+        f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", f->fft_grid));
     }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");

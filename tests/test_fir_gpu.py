@@ -95,6 +95,24 @@ def test_partitioned_long_filters(ntaps):
     assert rel_err(y, O.fir(taps, x)) <= TOL
 
 
+@pytest.mark.parametrize("grid", [3, 7, 0])
+@pytest.mark.parametrize("ntaps,cplx", [(4095, True), (4095, False), (2050, False), (3001, True)])
+def test_two_partition_spectrum_cache(monkeypatch, ntaps, cplx, grid):
+    """2050..4096 taps: every workgroup walks a contiguous run of tiles and reuses the
+    previous tile's spectrum.  A grid of 3 or 7 workgroups makes the runs long and makes
+    them cross channel boundaries (where the cached spectrum must be rebuilt)."""
+    if grid:
+        monkeypatch.setenv("SDR_AMD_FFT_GRID", str(grid))
+    rng = np.random.default_rng(ntaps + grid)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps)).astype(np.float32)
+    C, n = 5, 50000
+    x = np.stack([rand(rng, n, cplx) for _ in range(C)])
+    st = sdr_amd.FirState(taps, cplx, channels=C)
+    y = np.concatenate([sdr_amd.fir(st, x[:, :30001]), sdr_amd.fir(st, x[:, 30001:])], axis=1)
+    for c in range(C):
+        assert rel_err(y[c], O.fir(taps, x[c])) <= TOL, c
+
+
 @pytest.mark.parametrize("kind,ntaps,cplx", CASES)
 def test_single_call_vs_oracle(kind, ntaps, cplx):
     rng = np.random.default_rng(ntaps * 2 + cplx)
