@@ -51,8 +51,8 @@ WORKLOADS = {
     # fused chains (sdr_chain_*): handled by bench_chain() below
     "c4chain": ("64 channels x 2^22 real samples, hilbert(127, delay skip) + lowpass(127) fused in one pass "
                 "(BASELINE configs[3])", False, None, 22, 64),
-    "c5": ("fused gen(sine) -> hilbert(127) -> lowpass(127): 2^29 real outputs per GPU, generated on device in "
-           "2^24-sample chunks that never leave the GPU (BASELINE configs[4], per-GPU share)", False, None, 29, 1),
+    "c5": ("fused gen(sine) -> hilbert(127) -> lowpass(127): 2^29 real outputs per GPU, samples synthesised inside "
+           "the FIR kernel (BASELINE configs[4], per-GPU share)", False, None, 29, 1),
 }
 
 
@@ -79,16 +79,28 @@ def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
         chunk = blocks_per_chunk * B
         nchunks = n // chunk
         gen = S.Gen("sine", False, 1.0, float(np.float32(100e3) / np.float32(1e6)), 0.0, B, device=local_rank)
-        buf = torch.empty(chunk, dtype=torch.float32, device=dev)
+        buf = torch.empty(chunk if args.unfused else 1, dtype=torch.float32, device=dev)
         y = torch.empty(nchunks * chunk, dtype=torch.float32, device=dev)
 
-        def step():
-            for i in range(nchunks):
-                gen.generate_device(blocks_per_chunk, buf.data_ptr(), stream=stream)
-                chain.process_device(buf.data_ptr(), chunk, y.data_ptr() + 4 * i * chunk, stream=stream)
+        if args.unfused:
+            def step():
+                for i in range(nchunks):
+                    gen.generate_device(blocks_per_chunk, buf.data_ptr(), stream=stream)
+                    chain.process_device(buf.data_ptr(), chunk, y.data_ptr() + 4 * i * chunk, stream=stream)
+        else:
+            # the generator runs inside the FIR kernel: 4 bytes written per output, none read
+            chain.generate_device(gen, 8, y.data_ptr(), stream=stream)  # start-of-stream warm-up packets
+            for _ in range(4):  # every slot of the generator's phase-table ring at its working size
+                chain.generate_device(gen, blocks_per_chunk, y.data_ptr(), stream=stream)
+
+            def step():
+                for i in range(nchunks):
+                    chain.generate_device(gen, blocks_per_chunk, y.data_ptr() + 4 * i * chunk, stream=stream)
         bytes_per_step = nchunks * chunk * 4
         units = nchunks * chunk
-    return step, units, bytes_per_step, "sdr_chain(253 fused taps) -> " + "fir_fft4096_interior<REAL>", 253, desc
+    name = "sdr_chain(253 fused taps) -> fir_fft4096_interior<REAL%s>" % (
+        ", GEN" if args.workload == "c5" and not args.unfused else "")
+    return step, units, bytes_per_step, name, 253, desc
 
 
 
@@ -151,7 +163,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=27)
-    ap.add_argument("--chunk-log2", type=int, default=26, help="c5: samples per generated chunk")
+    ap.add_argument("--chunk-log2", type=int, default=29, help="c5: samples per call")
+    ap.add_argument("--unfused", action="store_true", help="c5: generator kernel + chain kernel through an HBM buffer")
     args = ap.parse_args()
 
     import torch

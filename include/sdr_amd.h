@@ -155,6 +155,19 @@ int sdr_gen_generate_device(sdr_gen_t* g, size_t blocks, void* d_out, void* hip_
 int sdr_gen_generate(sdr_gen_t* g, size_t blocks, void* out);
 void sdr_gen_destroy(sdr_gen_t* g);
 
+/* Replaces the whole pipeline `gen ... mode=real | hilbert | stream-filter fir=...`
+ * (reference: blocks/gen.cpp:166-195 feeding blocks/hilbert.cpp:53-96 through a unix
+ * pipe): the chain's outputs for the generator's next `blocks` packets, with the
+ * samples synthesised inside the FIR kernel -- no generated or intermediate stream is
+ * written to memory (the few packets that overlap the start-of-stream warm-up are
+ * materialised once, in a buffer the first call allocates).  Same results as
+ * sdr_gen_generate_device followed by sdr_chain_process_device.  Real generator,
+ * real one-channel chain whose combined filter has >= 64 taps, packets of 256..2^23
+ * samples; *n_out outputs are written from d_out (DEVICE memory), asynchronously on
+ * hip_stream. */
+int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t blocks, void* d_out, size_t* n_out,
+                              void* hip_stream);
+
 /* Pinned host memory (replaces the reference's SampleAllocator,
  * include/sdr/signal.hpp:41-69, for buffers that feed the GPU). */
 void* sdr_host_alloc(size_t bytes);

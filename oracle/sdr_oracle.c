@@ -255,7 +255,27 @@ void sdro_gen_real(float* out, size_t blocks, size_t block_size, float amp,
         float base = waveform == 0 ? phi + 0.25f : phi;
         for (size_t i = 0; i < block_size; ++i) {
             float arg = base + cps * (float)(int)i;
-            out[b * block_size + i] = amp * sdro_fastsin(fract_f(arg) * TWO_PI_F);
+            float w;
+            switch (waveform) {
+                case 2: /* squarenorm, libs/kfr/dsp/oscillators.hpp:64-73 */
+                    w = fract_f(arg) < 0.5f ? 1.0f : -1.0f;
+                    break;
+                case 3: { /* trianglenorm, oscillators.hpp:107-116: 1 - |4 fract(x + 0.25) - 2|.
+                           * The reference's release build (-ffast-math) folds the +0.25 out of
+                           * the fraction: 4 (x - floor(x + 0.25)) - 1, which keeps the bits the
+                           * literal form loses when x + 0.25 is rounded (up to 1.3e-5 of RMS at
+                           * x ~ 40); the golden packets pin this form. */
+                    float fl = floorf(arg + 0.25f);
+                    w = 1.0f - fabsf(4.0f * (arg - fl) - 1.0f);
+                    break;
+                }
+                case 4: /* sawtoothnorm, oscillators.hpp:80-89: 1 - 2 fract(x) */
+                    w = 1.0f - 2.0f * fract_f(arg);
+                    break;
+                default: /* sinenorm, oscillators.hpp:48-57 */
+                    w = sdro_fastsin(fract_f(arg) * TWO_PI_F);
+            }
+            out[b * block_size + i] = amp * w;
         }
         phi = fract_f(phi + phi_incr);
     }

@@ -15,8 +15,8 @@ compute calls raise.
 """
 from ._capi import (SdrError, FirState, fir, hilbert, fir_lowpass, fir_highpass, fir_bandpass,
                     fir_bandstop, fir_design, lib, lib_path, device_count, version,
-                    host_alloc, host_free, SDR_REAL, SDR_COMPLEX, Chain, Gen, optimal_block_size)
+                    host_alloc, host_free, SDR_REAL, SDR_COMPLEX, Chain, Gen, optimal_block_size, WAVEFORMS)
 
 __all__ = ["SdrError", "FirState", "fir", "hilbert", "fir_lowpass", "fir_highpass", "fir_bandpass",
            "fir_bandstop", "fir_design", "lib", "lib_path", "device_count", "version",
-           "host_alloc", "host_free", "SDR_REAL", "SDR_COMPLEX", "Chain", "Gen", "optimal_block_size"]
+           "host_alloc", "host_free", "SDR_REAL", "SDR_COMPLEX", "Chain", "Gen", "optimal_block_size", "WAVEFORMS"]

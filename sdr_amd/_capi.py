@@ -56,6 +56,7 @@ def lib():
         L.sdr_chain_destroy.restype = None
         L.sdr_chain_ntaps.argtypes = [vp]
         L.sdr_chain_ntaps.restype = sz
+        L.sdr_chain_generate_device.argtypes = [vp, vp, sz, vp, C.POINTER(sz), vp]
         L.sdr_gen_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, sz, C.c_int]
         L.sdr_gen_set_frequency.argtypes = [vp, C.c_float]
         L.sdr_gen_generate_device.argtypes = [vp, sz, vp, vp]
@@ -254,6 +255,13 @@ class Chain:
         _check(lib().sdr_chain_process_device(self._h, d_in, n if in_stride is None else in_stride, n, d_out,
                                               n if out_stride is None else out_stride, C.byref(n_out),
                                               C.c_void_p(stream or 0)))
+        return n_out.value
+
+    def generate_device(self, gen, blocks, d_out, stream=None):
+        """The chain's outputs for the next `blocks` packets of `gen` (a Gen), synthesised
+        inside the FIR kernel; returns the number of outputs written at d_out."""
+        n_out = C.c_size_t(0)
+        _check(lib().sdr_chain_generate_device(self._h, gen._h, blocks, d_out, C.byref(n_out), C.c_void_p(stream or 0)))
         return n_out.value
 
     def process_tensor(self, x, out=None):

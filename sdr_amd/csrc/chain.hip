@@ -19,6 +19,7 @@
 
 #include "../../include/sdr_amd.h"
 #include "errors.h"
+#include "handles.h"
 
 using sdr_amd::fail;
 
@@ -36,6 +37,8 @@ struct sdr_chain {
     size_t pos = 0;        // inputs consumed so far
     size_t emitted = 0;    // outputs produced so far
     float* scratch[3] = {nullptr, nullptr, nullptr}; // [channels][prefix] each
+    float* warm_in = nullptr; // sdr_chain_generate_device: the generated packets that cover the warm-up prefix
+    size_t warm_cap = 0;      // floats
 };
 
 static int hipfail(hipError_t e, const char* what) {
@@ -48,6 +51,7 @@ extern "C" void sdr_chain_destroy(sdr_chain_t* c) {
     sdr_fir_destroy(c->fused);
     for (float* p : c->scratch)
         if (p) (void)hipFree(p);
+    if (c->warm_in) (void)hipFree(c->warm_in);
     delete c;
 }
 
@@ -178,5 +182,54 @@ extern "C" int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t
     c->pos += n;
     c->emitted += produced;
     if (n_out) *n_out = produced;
+    return SDR_OK;
+}
+
+extern "C" int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t blocks, void* d_out, size_t* n_out,
+                                         void* hip_stream) {
+    if (n_out) *n_out = 0;
+    if (!c || !g) return fail(SDR_ERR_INVALID, "sdr_chain_generate_device: NULL handle");
+    int rc = sdr_amd::fir_generated_supported(c->fused, g);
+    if (rc != SDR_OK) return rc;
+    if (blocks == 0) return SDR_OK;
+    if (!d_out) return fail(SDR_ERR_INVALID, "sdr_chain_generate_device: NULL buffer");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const size_t B = sdr_amd::gen_block_size(g);
+    float* out = (float*)d_out;
+    size_t done = 0;
+
+    // The packets that overlap the start-of-stream region (swallowed outputs, staged
+    // warm-up) are materialised once and take the ordinary path.
+    const size_t lead = std::max(c->prefix, c->total_skip);
+    if (c->pos < lead) {
+        const size_t k = std::min(blocks, (lead - c->pos + B - 1) / B);
+        if (k * B > c->warm_cap) {
+            int prev = 0;
+            (void)hipGetDevice(&prev);
+            (void)hipSetDevice(c->device);
+            if (c->warm_in) (void)hipFree(c->warm_in);
+            c->warm_in = nullptr;
+            c->warm_cap = 0;
+            hipError_t e = hipMalloc(&c->warm_in, k * B * sizeof(float));
+            (void)hipSetDevice(prev);
+            if (e != hipSuccess) return hipfail(e, "hipMalloc(chain warm-up input)");
+            c->warm_cap = k * B;
+        }
+        rc = sdr_gen_generate_device(g, k, c->warm_in, stream);
+        if (rc != SDR_OK) return rc;
+        size_t n1 = 0;
+        rc = sdr_chain_process_device(c, c->warm_in, k * B, k * B, out, k * B, &n1, stream);
+        if (rc != SDR_OK) return rc;
+        done = n1;
+        blocks -= k;
+    }
+    if (blocks) {
+        rc = sdr_amd::fir_process_generated(c->fused, g, blocks, out + done, stream);
+        if (rc != SDR_OK) return rc;
+        c->pos += blocks * B;
+        c->emitted += blocks * B;
+        done += blocks * B;
+    }
+    if (n_out) *n_out = done;
     return SDR_OK;
 }

@@ -240,10 +240,14 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // contiguous run of tiles and keeps X_(b-1) -- the spectrum it computed for the
 // previous tile -- in registers, so a tile costs one forward and one inverse
 // transform instead of two forward and one inverse.
-template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE>
+// GEN (real signals): the input is synthesised in registers by the reference
+// generator's recipe (gen_device.h) instead of being loaded -- the fused
+// gen -> hilbert -> FIR chain writes 4 bytes per sample and reads none.
+template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE, bool GEN>
 __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_interior(FftArgs a) {
     static_assert(!LONG || HB == 8, "partitioned mode uses hop 2048");
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
+    static_assert(!GEN || REAL, "the generator source produces real samples");
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     const int tid = threadIdx.x;
     LaneConstsT<TBL> c;
@@ -286,6 +290,71 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
             }
         }
     };
+    // GEN: the pair (x[o + 256 n2 + tid], x[o + D + 256 n2 + tid]) for n2 = 0..15 (o >= 0,
+    // wave-uniform).  A row of 256 consecutive samples touches at most two generator
+    // blocks (B >= 256): both phases come through scalar loads, the lane picks one.
+    struct Cursor { long long b; int rb; }; // block and in-block offset of a row's first sample
+    auto cursor_at = [&](long long o) {
+        const int B = (int)a.gen.block_size;
+        long long b = (long long)((double)o * a.gen.inv_block);
+        long long r = o - b * B;
+        if (r < 0) { r += B; --b; }
+        else if (r >= B) { r -= B; ++b; }
+        return Cursor{b, (int)r};
+    };
+    auto synth = [&](long long o, f2 (&dst)[16]) {
+        const int B = (int)a.gen.block_size;
+        Cursor c0 = cursor_at(o), c1 = cursor_at(o + D);
+        auto next_row = [&](Cursor& c) {
+            c.rb += 256;
+            if (c.rb >= B) { c.rb -= B; ++c.b; }
+        };
+        if (a.gen.waveform <= 1) {
+            // sine / cosine: straight-line polynomial on both members at once; the lane's
+            // in-block index is formed in float (tid + row offset: exact small integers)
+            const float tidf = (float)tid;
+            auto lane = [&](const Cursor& c, float& idx) {
+                const float pa = a.gen.phi[c.b], pb = a.gen.phi[c.b + 1];
+                const bool wrap = tid >= B - c.rb;
+                idx = tidf + (wrap ? (float)(c.rb - B) : (float)c.rb);
+                return wrap ? pb : pa;
+            };
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) {
+                float i0, i1;
+                const float p0 = lane(c0, i0), p1 = lane(c1, i1);
+                dst[n2] = gen_sine_pair(a.gen.amp, a.gen.cps, f2{p0, p1}, f2{i0, i1});
+                next_row(c0);
+                next_row(c1);
+            }
+        } else {
+            auto lane = [&](const Cursor& c, int& i) { // in-block index and start phase of this lane's sample
+                const float pa = a.gen.phi[c.b], pb = a.gen.phi[c.b + 1];
+                i = c.rb + tid;
+                const bool wrap = i >= B;
+                i = wrap ? i - B : i;
+                return wrap ? pb : pa;
+            };
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) {
+                int i0, i1;
+                const float p0 = lane(c0, i0), p1 = lane(c1, i1);
+                dst[n2] = f2{gen_real_sample(a.gen.waveform, a.gen.amp, a.gen.cps, p0, i0),
+                             gen_real_sample(a.gen.waveform, a.gen.amp, a.gen.cps, p1, i1)};
+                next_row(c0);
+                next_row(c1);
+            }
+        }
+    };
+    // the tile's 4096-point window, `back` samples earlier (previous windows of the
+    // partitioned mode): loaded, or synthesised
+    auto fetch = [&](Pos p, long long back, f2 (&dst)[16]) {
+        if constexpr (GEN) {
+            synth(first_out(p) - 256 * HB - back, dst);
+        } else {
+            load(in_ptr(p) - back * W, dst);
+        }
+    };
 
     if (inner <= 0 || (long long)blockIdx.x >= total) return;
     Pos cur{0, 0};
@@ -303,32 +372,36 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
         cur.tt = a.t_lo + blockIdx.x;
         while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
     }
-    f2 nx[16];
-    load(in_ptr(cur), nx);
+    f2 nx[GEN ? 1 : 16]; // the next tile's points, loaded one tile ahead (nothing to prefetch with GEN)
+    if constexpr (!GEN) load(in_ptr(cur), nx);
 
     auto body = [&]() {
         f2 v[16];
         if (CACHE && prev_ch != cur.ch) {
             // start of a run or of a channel: transform window b-1 once
-            load(in_ptr(cur) - 2048 * W, v);
+            fetch(cur, 2048, v);
             forward_tile(v, lds, tid, c, [] {});
 #pragma unroll
             for (int k = 0; k < 16; ++k) prev[CACHE ? k : 0] = v[P16(k)];
             prev_ch = cur.ch;
         }
+        if constexpr (GEN) {
+            fetch(cur, 0, v);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = nx[i];
+            for (int i = 0; i < 16; ++i) v[i] = nx[GEN ? 0 : i];
+        }
         // past the end the workgroup re-loads its own tile (harmless): keeps the body branch-free
         Pos nxt = advance(cur);
         if (CACHE ? left <= 1 : nxt.ch >= a.channels) nxt = cur;
         const float* pn = in_ptr(nxt);
         f2 w[16];
         if (a.ablate & 1) {
-            load(pn, nx);
+            if constexpr (!GEN) load(pn, nx);
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[P16(k)] = v[k];
         } else {
-            forward_tile(v, lds, tid, c, [&] { load(pn, nx); });
+            forward_tile(v, lds, tid, c, [&] { if constexpr (!GEN) load(pn, nx); });
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
             if (CACHE) {
@@ -339,7 +412,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
                 }
             } else if (LONG) {
                 for (int p = 1; p < a.parts; ++p) {
-                    load(in_ptr(cur) - (long long)p * 2048 * W, v); // window b-p (L2 resident)
+                    fetch(cur, (long long)p * 2048, v); // window b-p (L2 resident)
                     forward_tile(v, lds, tid, c, [] {});
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
@@ -375,8 +448,9 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
 // ---- edge tiles: the first tile(s) of every channel (they read the carried history)
 // and the tiles from the last full one on (partial outputs); also every tile of a
 // short call.  Bounds-checked, runtime halo / parts, no pipelining.
-template <bool REAL>
+template <bool REAL, bool GEN>
 __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
+    static_assert(!GEN || REAL, "the generator source produces real samples");
     __shared__ __align__(16) f2 lds[16 * ROW];
     const int tid = threadIdx.x;
     LaneConstsT<false> c;
@@ -400,7 +474,9 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
         const long long o0 = tt * per_tile; // first output of the tile
         auto sample = [&](long long m, int k) -> float { // virtual stream: history | input | 0
             if (m < 0) { const long long h = a.hist_len + m; return h >= 0 ? hist[h * W + k] : 0.0f; }
-            return m < a.n ? in[m * W + k] : 0.0f;
+            if (m >= a.n) return 0.0f;
+            if constexpr (GEN) return gen_src_at(a.gen, m);
+            else return in[m * W + k];
         };
         f2 w[16];
         for (int p = 0; p < a.parts; ++p) {
@@ -436,26 +512,43 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
     }
 }
 
-template <bool REAL>
+template <bool REAL, bool GEN>
 static hipError_t launch_interior(const FftArgs& a, long long grid, hipStream_t stream) {
     const dim3 g((unsigned)grid), b(256);
     if (a.parts == 2 && !(a.ablate & 4)) {
-        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, true, true>), g, b, 0, stream, a);
+        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, true, true, GEN>), g, b, 0, stream, a);
         return hipGetLastError();
     }
     if (a.parts > 1) {
-        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, false, false>), g, b, 0, stream, a);
+        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, false, false, GEN>), g, b, 0, stream, a);
         return hipGetLastError();
     }
     // W_256 twiddles from the LDS table: 161 VGPRs, three workgroups per CU (+3 % over
     // the all-register build at two per CU, profiles/r01_fft_variants.txt)
     switch (a.halo / 256) {
-        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false, true, false>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false, true, false>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false, true, false>), g, b, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false, true, false>), g, b, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false, true, false, GEN>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// History after a synthesised call: virtual samples n-hist_len .. n-1 (old history where < 0).
+__global__ void fir_carry_history_gen(GenSrc g, long long n, const float* __restrict__ old_hist,
+                                      float* __restrict__ new_hist, int hist_len) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < hist_len; s += gridDim.x * blockDim.x) {
+        const long long m = n - hist_len + s;
+        new_hist[s] = m >= 0 ? gen_src_at(g, m) : old_hist[hist_len + m];
+    }
+}
+
+hipError_t launch_carry_history_gen(const GenSrc& g, long long n, const float* old_hist, float* new_hist,
+                                    int hist_len, hipStream_t stream) {
+    const int blocks = (hist_len + 255) / 256;
+    hipLaunchKernelGGL(fir_carry_history_gen, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, g, n, old_hist,
+                       new_hist, hist_len);
     return hipGetLastError();
 }
 
@@ -471,6 +564,8 @@ void fir_fft_plan(size_t ntaps, int* halo, int* parts) {
 
 hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStream_t stream) {
     if (a0.n == 0 || a0.channels == 0) return hipSuccess;
+    if (a0.gen.enabled && (!real || a0.channels != 1 || a0.gen.block_size < 256 || a0.gen.block_size > (1 << 23)))
+        return hipErrorInvalidValue;
     FftArgs a = a0;
     const long long L = FFT_N - a.halo;
     const long long per_tile = real ? 2 * L : L;
@@ -488,14 +583,16 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
         const long long total = inner * a.channels;
         const long long rounds = (total + grid_blocks - 1) / grid_blocks;
         const long long grid = (total + rounds - 1) / rounds;
-        e = real ? launch_interior<true>(a, grid, stream) : launch_interior<false>(a, grid, stream);
+        if (a.gen.enabled) e = launch_interior<true, true>(a, grid, stream);
+        else e = real ? launch_interior<true, false>(a, grid, stream) : launch_interior<false, false>(a, grid, stream);
         if (e != hipSuccess) return e;
     }
     const long long edge = (tiles_per_ch - inner) * a.channels;
     if (edge > 0) {
         long long grid = edge < grid_blocks ? edge : grid_blocks;
-        if (real) hipLaunchKernelGGL(fir_fft4096_edge<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(fir_fft4096_edge<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+        if (a.gen.enabled) hipLaunchKernelGGL((fir_fft4096_edge<true, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        else if (real) hipLaunchKernelGGL((fir_fft4096_edge<true, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((fir_fft4096_edge<false, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
         e = hipGetLastError();
     }
     return e;

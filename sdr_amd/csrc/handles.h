@@ -1,0 +1,19 @@
+// handles.h -- internal: what chain.hip needs from the FIR and generator handles
+// that live in sdr_capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "../../include/sdr_amd.h"
+
+namespace sdr_amd {
+
+// Like sdr_fir_process_device with the generator's next `blocks` packets as the input,
+// synthesised inside the FIR kernel (nothing is written but the blocks*B outputs).
+// Needs the overlap-save path, real samples, one channel, 256 <= B <= 2^23.
+int fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, float* d_out, hipStream_t stream);
+// SDR_OK when fir_process_generated would accept the pair, else the error (message set).
+int fir_generated_supported(const sdr_fir_t* f, const sdr_gen_t* g);
+size_t gen_block_size(const sdr_gen_t* g);
+
+} // namespace sdr_amd

@@ -14,6 +14,7 @@
 #include "errors.h"
 #include "fir_kernels.h"
 #include "gen_kernels.h"
+#include "handles.h"
 
 namespace sdr_amd {
 
@@ -260,7 +261,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
     if (((uintptr_t)d_in % wbytes) || ((uintptr_t)d_out % wbytes))
         return fail(SDR_ERR_INVALID, "sdr_fir_process_device: buffers must be aligned to the sample size");
     if (f->use_fft) {
-        FftArgs fa;
+        FftArgs fa = {};
         fa.in = d_in;
         fa.out = d_out;
         fa.hist = f->d_hist[f->cur];
@@ -418,6 +419,7 @@ struct sdr_gen {
     static constexpr int kRing = 4;
     struct Table {
         hipEvent_t free = nullptr; // recorded after the kernel that reads the table
+        hipEvent_t ready = nullptr; // recorded after the table's upload on the generator's own stream
         float* h = nullptr;        // pinned
         float* d = nullptr;
         size_t cap = 0;
@@ -469,8 +471,10 @@ extern "C" int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, fl
     DeviceGuard guard(device);
     hipError_t e;
     e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
-    for (auto& t : g->table)
+    for (auto& t : g->table) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&t.free, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         int rc = hip_fail(e, "sdr_gen_create");
         std::string keep = g_last_error;
@@ -490,32 +494,59 @@ extern "C" int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample) {
     return SDR_OK;
 }
 
-static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
-    if (blocks == 0) return SDR_OK;
+// The next `blocks` per-block start phases (plus one spare entry, read but never used
+// by kernels that look one block ahead) into the next table of the ring, uploaded on
+// `stream`.  The caller records t->free after the kernels that read the table.
+// fused: the table feeds a FIR kernel's generator source, which for cosine expects the
+// quarter-cycle advance (gen.cpp:184: phi + 0.25f, one fp32 addition per block) in the table.
+static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen::Table** out, bool fused = false) {
     sdr_gen::Table& t = g->table[g->next_table];
     g->next_table = (g->next_table + 1) % sdr_gen::kRing;
     SDR_HIP(hipEventSynchronize(t.free)); // the call that used this slot 4 calls ago
-    if (blocks > t.cap) {
+    if (blocks + 1 > t.cap) {
         if (t.h) (void)hipHostFree(t.h);
         if (t.d) (void)hipFree(t.d);
         t.h = t.d = nullptr;
         t.cap = 0;
-        const size_t cap = std::max<size_t>(blocks, 4096);
+        const size_t cap = std::max<size_t>(blocks + 1, 4096);
         SDR_HIP(hipHostMalloc(&t.h, cap * sizeof(float), hipHostMallocDefault));
         SDR_HIP(hipMalloc(&t.d, cap * sizeof(float)));
         t.cap = cap;
     }
     // sequential fp32 phase recurrence, one value per block (gen.cpp:185,192,227)
+    // phi and phi_incr lie in [0,1), so their fp32 sum s lies in [0,2) and
+    // fract(s) = s - floor(s) is s or s - 1 (exact): no libm call on this serial chain,
+    // which the host must finish faster than the GPU consumes a table (one entry per
+    // block_size samples).
     float phi = g->phi;
+    const float incr = g->phi_incr;
+    float* h = t.h;
+    const float quarter = fused && g->waveform == SDR_WAVE_COSINE ? 0.25f : 0.0f;
     for (size_t b = 0; b < blocks; ++b) {
-        t.h[b] = phi;
-        phi = fractf_host(phi + g->phi_incr);
+        h[b] = phi + quarter;
+        const float s = phi + incr;
+        phi = s >= 1.0f ? s - 1.0f : s;
+        if (__builtin_expect(phi >= 1.0f, 0)) phi -= 1.0f; // only if a fract() above rounded up to 1.0
     }
+    h[blocks] = phi;
     g->phi = phi;
-    SDR_HIP(hipMemcpyAsync(t.d, t.h, blocks * sizeof(float), hipMemcpyHostToDevice, stream));
+    // upload on the generator's own stream: the host runs ahead of the GPU, so table k+1
+    // crosses PCIe while the kernels of call k are still running on `stream`
+    SDR_HIP(hipMemcpyAsync(t.d, t.h, (blocks + 1) * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    SDR_HIP(hipEventRecord(t.ready, g->stream));
+    SDR_HIP(hipStreamWaitEvent(stream, t.ready, 0));
+    *out = &t;
+    return SDR_OK;
+}
+
+static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
+    if (blocks == 0) return SDR_OK;
+    sdr_gen::Table* t = nullptr;
+    int rc = gen_next_table(g, blocks, stream, &t);
+    if (rc != SDR_OK) return rc;
     GenArgs a;
     a.out = d_out;
-    a.phi = t.d;
+    a.phi = t->d;
     a.blocks = (long long)blocks;
     a.block_size = (long long)g->block_size;
     a.amp = g->amp;
@@ -523,7 +554,54 @@ static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t 
     a.waveform = g->waveform;
     a.complex_samples = g->kind == SDR_COMPLEX;
     SDR_HIP(launch_gen(a, stream));
-    SDR_HIP(hipEventRecord(t.free, stream));
+    SDR_HIP(hipEventRecord(t->free, stream));
+    return SDR_OK;
+}
+
+size_t sdr_amd::gen_block_size(const sdr_gen_t* g) { return g ? g->block_size : 0; }
+
+int sdr_amd::fir_generated_supported(const sdr_fir_t* f, const sdr_gen_t* g) {
+    if (!f || !g) return fail(SDR_ERR_INVALID, "fused generator: NULL handle");
+    if (f->device != g->device) return fail(SDR_ERR_INVALID, "fused generator: generator and filter live on different devices");
+    if (g->kind != SDR_REAL || f->kind != SDR_REAL || f->channels != 1)
+        return fail(SDR_ERR_INVALID, "fused generator: needs a real generator and a real one-channel filter");
+    if (!f->use_fft) return fail(SDR_ERR_INVALID, "fused generator: the filter is too short for the overlap-save kernels");
+    if (g->block_size < 256 || g->block_size > (1u << 23))
+        return fail(SDR_ERR_INVALID, "fused generator: block size must be 256..2^23 samples");
+    return SDR_OK;
+}
+
+int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, float* d_out, hipStream_t stream) {
+    int rc = fir_generated_supported(f, g);
+    if (rc != SDR_OK) return rc;
+    if (blocks == 0) return SDR_OK;
+    DeviceGuard guard(f->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    sdr_gen::Table* t = nullptr;
+    rc = gen_next_table(g, blocks, stream, &t, true);
+    if (rc != SDR_OK) return rc;
+    FftArgs fa = {};
+    fa.in = nullptr;
+    fa.out = d_out;
+    fa.hist = f->d_hist[f->cur];
+    fa.hperm = f->d_hperm;
+    fa.n = (long long)(blocks * g->block_size);
+    fa.in_stride = fa.out_stride = fa.n;
+    fa.channels = 1;
+    fa.halo = f->fft_halo;
+    fa.hist_len = f->hist_len;
+    fa.parts = f->fft_parts;
+    fa.gen.phi = t->d;
+    fa.gen.block_size = (long long)g->block_size;
+    fa.gen.inv_block = 1.0 / (double)g->block_size;
+    fa.gen.amp = g->amp;
+    fa.gen.cps = g->cps;
+    fa.gen.waveform = g->waveform;
+    fa.gen.enabled = 1;
+    SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
+    SDR_HIP(launch_carry_history_gen(fa.gen, fa.n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1], f->hist_len, stream));
+    f->cur ^= 1;
+    SDR_HIP(hipEventRecord(t->free, stream));
     return SDR_OK;
 }
 
@@ -567,6 +645,7 @@ extern "C" void sdr_gen_destroy(sdr_gen_t* g) {
         if (t.h) (void)hipHostFree(t.h);
         if (t.d) (void)hipFree(t.d);
         if (t.free) (void)hipEventDestroy(t.free);
+        if (t.ready) (void)hipEventDestroy(t.ready);
     }
     if (g->d_out) (void)hipFree(g->d_out);
     if (g->stream) (void)hipStreamDestroy(g->stream);

@@ -69,6 +69,12 @@ gens = {
     "complex_cosine_100k_1M": ["freq=100k", "sample_rate=1M"],
     "complex_sine_1k_48000_amp05_phi30": ["freq=1k", "waveform=sine", "sample_rate=48000", "amp=0.5", "phi=30"],
     "real_sine_stream5_7k_250k": ["7k", "hz", "sine", "sample_rate=250k", "mode=real", "stream=5"],
+    "real_square_100k_1M": ["freq=100k", "waveform=square", "sample_rate=1M", "mode=real"],
+    "real_triangle_1k_48000_amp05_phi30": ["freq=1k", "waveform=triangle", "sample_rate=48000", "mode=real", "amp=0.5", "phi=30"],
+    "real_sawtooth_7k_250k": ["freq=7k", "waveform=sawtooth", "sample_rate=250k", "mode=real"],
+    "complex_square_100k_1M": ["freq=100k", "waveform=square", "sample_rate=1M"],
+    "complex_triangle_1k_48000_amp05_phi30_taps31": ["freq=1k", "waveform=triangle", "sample_rate=48000", "amp=0.5", "phi=30", "hilbert_taps=31"],
+    "complex_sawtooth_neg7k_250k": ["freq=-7k", "waveform=sawtooth", "sample_rate=250k"],
 }
 g = {}
 for k, args in gens.items():

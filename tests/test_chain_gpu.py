@@ -101,7 +101,7 @@ def test_gen_device_matches_oracle_recipe():
     B = sdr_amd.optimal_block_size(4, 1000000)
     assert B == 2044
     cps = float(np.float32(100e3) / np.float32(1e6))
-    for wf, code in (("sine", 1), ("cosine", 0)):
+    for wf, code in (("sine", 1), ("cosine", 0), ("square", 2), ("triangle", 3), ("sawtooth", 4)):
         g = sdr_amd.Gen(wf, False, 0.75, cps, 30.0, B)
         a = np.concatenate([g.generate(3), g.generate(70)])   # phase carries across calls
         phi0 = np.float32(30.0) / np.float32(360.0)
@@ -141,3 +141,72 @@ def test_fused_gen_chain_config5_small():
     x, _ = O.gen_real(blocks, B, 1.0, cps, 0.0, 1)
     ref = staged_oracle(stages, x)
     assert got.shape == ref.shape and rel_err(got, ref) <= TOL
+
+
+FUSED_CASES = [
+    # waveform, amp, phase, sample_rate (sets B), second-stage taps, calls (blocks each)
+    ("sine", 1.0, 0.0, 1000000, 127, [40]),
+    ("sine", 1.0, 0.0, 1000000, 127, [1, 2, 30, 7]),
+    ("cosine", 0.75, 30.0, 48000, 255, [3, 37]),
+    ("square", 1.0, 0.0, 1000000, 127, [25]),
+    ("triangle", 0.5, 90.0, 1000000, 127, [25]),
+    ("sawtooth", 1.0, 0.0, 1000000, 127, [25]),
+    ("sine", 1.0, 0.0, 1000000, 4095, [6, 60]),     # two partitions: cached-spectrum kernel
+    ("sine", 1.0, 0.0, 1000000, 9001, [70]),        # five partitions
+]
+
+
+@pytest.mark.parametrize("wf,amp,phase,rate,ntaps2,calls", FUSED_CASES)
+def test_generator_fused_into_the_fir_kernel(wf, amp, phase, rate, ntaps2, calls):
+    """sdr_chain_generate_device: gen -> hilbert(127, skip 63) -> FIR with the samples
+    synthesised inside the FIR kernel.  Must equal the unfused device path (generate,
+    then filter) and the oracle's generator + staged filters."""
+    import torch
+    B = sdr_amd.optimal_block_size(4, rate)
+    cps = float(np.float32(100e3) / np.float32(rate)) if rate == 1000000 else float(np.float32(5e3) / np.float32(rate))
+    taps2 = sdr_amd.fir_lowpass(ntaps2, 0.12) if ntaps2 < 1000 else sdr_amd.fir_bandpass(ntaps2, 0.05, 0.2)
+    stages = [(sdr_amd.hilbert(127), 63), (taps2, 0)]
+    total = sum(calls)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gen = sdr_amd.Gen(wf, False, amp, cps, phase, B)
+    chain = sdr_amd.Chain(stages, False)
+    out = torch.full((total * B,), 777.0, dtype=torch.float32, device="cuda")
+    done = 0
+    for nb in calls:
+        done += chain.generate_device(gen, nb, out.data_ptr() + 4 * done, stream=stream)
+    torch.cuda.synchronize()
+    assert done == total * B - 63
+    assert bool((out[done:] == 777.0).all())   # nothing written past the outputs
+    fused = out[:done].cpu().numpy()
+
+    gen2 = sdr_amd.Gen(wf, False, amp, cps, phase, B)
+    chain2 = sdr_amd.Chain(stages, False)
+    buf = torch.empty(max(calls) * B, dtype=torch.float32, device="cuda")
+    parts = []
+    for nb in calls:
+        gen2.generate_device(nb, buf.data_ptr(), stream=stream)
+        o, n_out = chain2.process_tensor(buf[: nb * B])
+        torch.cuda.synchronize()
+        parts.append(o[:n_out].cpu().numpy())
+    unfused = np.concatenate(parts)
+    assert fused.shape == unfused.shape
+    assert rel_err(fused, unfused) <= 1e-6      # same samples, same tiles: only rounding-order noise at most
+
+    x, _ = O.gen_real(total, B, amp, cps, float(np.float32(phase) / np.float32(360.0)), sdr_amd.WAVEFORMS[wf])
+    ref = staged_oracle(stages, x)
+    assert fused.shape == ref.shape and rel_err(fused, ref) <= TOL
+
+
+def test_generator_fusion_rejects_what_it_cannot_do():
+    B = 2044
+    gen_c = sdr_amd.Gen("sine", True, 1.0, 0.1, 0.0, 1022)
+    gen_small = sdr_amd.Gen("sine", False, 1.0, 0.1, 0.0, 100)
+    gen = sdr_amd.Gen("sine", False, 1.0, 0.1, 0.0, B)
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.1), 0)]
+    import torch
+    out = torch.empty(4 * B, dtype=torch.float32, device="cuda")
+    for g, ch in ((gen_c, sdr_amd.Chain(stages, False)), (gen_small, sdr_amd.Chain(stages, False)),
+                  (gen, sdr_amd.Chain(stages, False, channels=2)), (gen, sdr_amd.Chain([(sdr_amd.hilbert(31), 15)], False))):
+        with pytest.raises(sdr_amd.SdrError):
+            ch.generate_device(g, 2, out.data_ptr())
