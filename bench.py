@@ -89,7 +89,16 @@ def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
                     chain.process_device(buf.data_ptr(), chunk, y.data_ptr() + 4 * i * chunk, stream=stream)
         else:
             # the generator runs inside the FIR kernel: 4 bytes written per output, none read
-            chain.generate_device(gen, 8, y.data_ptr(), stream=stream)  # start-of-stream warm-up packets
+            # rank r owns packets [first, first + blocks) of the world * 2^29-sample stream:
+            # generator and chain positioned there, primed with the halo packets
+            from sdr_amd import sharding
+            first, _, halo = sharding.plan_generated_chain(world * nchunks * blocks_per_chunk, world, B, 253)[rank]
+            if first:
+                gen.advance(first - halo)
+                chain.seek((first - halo) * B)
+                chain.generate_device(gen, halo, y.data_ptr(), stream=stream)   # outputs discarded
+            else:
+                chain.generate_device(gen, 8, y.data_ptr(), stream=stream)  # start-of-stream warm-up packets
             for _ in range(4):  # every slot of the generator's phase-table ring at its working size
                 chain.generate_device(gen, blocks_per_chunk, y.data_ptr(), stream=stream)
 

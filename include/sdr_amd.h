@@ -124,6 +124,14 @@ int sdr_chain_create(sdr_chain_t** out, size_t nstages, const float* const* taps
 int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t in_stride, size_t n, void* d_out,
                              size_t out_stride, size_t* n_out, void* hip_stream);
 int sdr_chain_reset(sdr_chain_t* c);
+/* Multi-GPU sharding of one long stream (no counterpart in the single-process
+ * reference): declare that `position` input samples of the stream were consumed
+ * elsewhere, so this handle is not at the start of the stream -- no group-delay skip
+ * and no warm-up are applied from here on.  Histories are zeroed: feed at least
+ * sdr_chain_ntaps()-1 samples preceding the first output you keep (their outputs are
+ * to be discarded).  position must lie beyond the start-of-stream region
+ * (>= sum of stage tap counts); 0 is the same as sdr_chain_reset. */
+int sdr_chain_seek(sdr_chain_t* c, size_t position);
 void sdr_chain_destroy(sdr_chain_t* c);
 /* Taps of the single equivalent filter (for tests). */
 size_t sdr_chain_ntaps(const sdr_chain_t* c);
@@ -146,6 +154,11 @@ int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, float amplitu
 /* New frequency from the next block on (the unit=stream control input,
  * blocks/gen.cpp:167-176). */
 int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample);
+/* The phase recurrence of the generator loop (blocks/gen.cpp:185 `phi = fract(phi +
+ * phi_incr)`) run `blocks` times without producing samples: positions the generator
+ * at packet `blocks` further on, bit-for-bit where the reference would be (a rank that
+ * owns a later chunk of the stream starts here). */
+int sdr_gen_advance(sdr_gen_t* g, size_t blocks);
 /* Replaces the body of the generator loop (blocks/gen.cpp:183-195, 224-229):
  * the next `blocks` packets' worth of samples, bit-for-bit the reference's fp32
  * recipe (polynomial sine, per-block phase recurrence), written to DEVICE

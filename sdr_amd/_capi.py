@@ -52,6 +52,8 @@ def lib():
         L.sdr_chain_create.argtypes = [C.POINTER(vp), sz, C.POINTER(fp), C.POINTER(sz), C.POINTER(sz), C.c_int, sz, C.c_int]
         L.sdr_chain_process_device.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz), vp]
         L.sdr_chain_reset.argtypes = [vp]
+        L.sdr_chain_seek.argtypes = [vp, sz]
+        L.sdr_gen_advance.argtypes = [vp, sz]
         L.sdr_chain_destroy.argtypes = [vp]
         L.sdr_chain_destroy.restype = None
         L.sdr_chain_ntaps.argtypes = [vp]
@@ -279,6 +281,10 @@ class Chain:
     def reset(self):
         _check(lib().sdr_chain_reset(self._h))
 
+    def seek(self, position):
+        """Not at the start of the stream: `position` inputs were consumed elsewhere."""
+        _check(lib().sdr_chain_seek(self._h, int(position)))
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib().sdr_chain_destroy(self._h)
@@ -312,6 +318,10 @@ class Gen:
 
     def generate_device(self, blocks, d_out, stream=None):
         _check(lib().sdr_gen_generate_device(self._h, blocks, d_out, C.c_void_p(stream or 0)))
+
+    def advance(self, blocks):
+        """Skip `blocks` packets (phase recurrence only)."""
+        _check(lib().sdr_gen_advance(self._h, int(blocks)))
 
     def set_frequency(self, cps):
         _check(lib().sdr_gen_set_frequency(self._h, cps))

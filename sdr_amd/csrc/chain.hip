@@ -128,6 +128,20 @@ extern "C" int sdr_chain_reset(sdr_chain_t* c) {
     return rc;
 }
 
+extern "C" int sdr_chain_seek(sdr_chain_t* c, size_t position) {
+    if (!c) return fail(SDR_ERR_INVALID, "sdr_chain_seek: NULL handle");
+    if (position == 0) return sdr_chain_reset(c);
+    size_t lead = std::max(c->prefix, c->total_skip);
+    if (position < lead + c->fused_ntaps)
+        return fail(SDR_ERR_INVALID, "sdr_chain_seek: position lies inside the start-of-stream region");
+    int rc = sdr_chain_reset(c);
+    if (rc != SDR_OK) return rc;
+    for (size_t& s : c->skip_left) s = 0;
+    c->pos = position;
+    c->emitted = position - c->total_skip;
+    return SDR_OK;
+}
+
 extern "C" int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t in_stride, size_t n, void* d_out,
                                         size_t out_stride, size_t* n_out, void* hip_stream) {
     if (!c) return fail(SDR_ERR_INVALID, "sdr_chain_process_device: NULL handle");

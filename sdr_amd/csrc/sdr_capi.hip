@@ -494,6 +494,16 @@ extern "C" int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample) {
     return SDR_OK;
 }
 
+extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
+    clear_error();
+    if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_advance: NULL handle");
+    float phi = g->phi;
+    const float incr = g->phi_incr;
+    for (size_t b = 0; b < blocks; ++b) phi = fractf_host(phi + incr);
+    g->phi = phi;
+    return SDR_OK;
+}
+
 // The next `blocks` per-block start phases (plus one spare entry, read but never used
 // by kernels that look one block ahead) into the next table of the ring, uploaded on
 // `stream`.  The caller records t->free after the kernels that read the table.

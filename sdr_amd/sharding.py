@@ -58,6 +58,25 @@ def filter_chunk(make_state, source, n_total, ntaps, rank, world, align=1):
     return start, y
 
 
+def plan_generated_chain(n_blocks, world, block_size, chain_ntaps):
+    """BASELINE config 5: a generated stream of n_blocks packets of block_size samples
+    through a fused chain of chain_ntaps combined taps, cut into whole packets.  Per
+    rank: (first_block, blocks, halo_blocks) -- the rank positions its generator at
+    packet first_block - halo_blocks (Gen.advance), seeks its chain to that sample
+    (Chain.seek; rank 0 starts the stream instead), discards the outputs of the
+    halo_blocks priming packets and keeps the next blocks * block_size outputs.  The
+    outputs of all ranks, in rank order, are the stream's outputs (rank 0's are
+    shorter by the chain's total group-delay skip)."""
+    halo = -(-(chain_ntaps - 1) // block_size)
+    plan = []
+    for first, cnt in plan_chunks(n_blocks, world, 1):
+        h = 0 if first == 0 else halo
+        if first and (first - h) * block_size < 4 * chain_ntaps:
+            raise ValueError("chunks this small would start inside the start-of-stream region")
+        plan.append((first, cnt, h))
+    return plan
+
+
 def gather_chunks(y, dist, dst=0):
     """Gather every rank's output slice on rank `dst` (torch.distributed, any
     backend; slices may differ in length).  Returns the list of slices on dst, None

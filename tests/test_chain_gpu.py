@@ -210,3 +210,39 @@ def test_generator_fusion_rejects_what_it_cannot_do():
                   (gen, sdr_amd.Chain(stages, False, channels=2)), (gen, sdr_amd.Chain([(sdr_amd.hilbert(31), 15)], False))):
         with pytest.raises(sdr_amd.SdrError):
             ch.generate_device(g, 2, out.data_ptr())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config5_sharding_recipe_on_one_gpu(world):
+    """BASELINE config 5's multi-GPU cut, rehearsed on one GPU: every "rank" positions
+    its own generator and chain (Gen.advance, Chain.seek), primes with its halo packets
+    and produces its share; the concatenation equals the stream produced in one go --
+    no sample dropped, duplicated or reordered at the chunk boundaries."""
+    import torch
+    from sdr_amd import sharding
+    B = 2044
+    cps = float(np.float32(100e3) / np.float32(1e6))
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.1), 0)]
+    n_blocks = 50
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def produce(first, blocks, halo):
+        gen = sdr_amd.Gen("sine", False, 1.0, cps, 0.0, B)
+        chain = sdr_amd.Chain(stages, False)
+        out = torch.empty((blocks + halo) * B, dtype=torch.float32, device="cuda")
+        if first:
+            gen.advance(first - halo)
+            chain.seek((first - halo) * B)
+            n0 = chain.generate_device(gen, halo, out.data_ptr(), stream=stream)   # priming: discarded
+            assert n0 == halo * B
+        n1 = chain.generate_device(gen, blocks, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        return out[:n1].cpu().numpy()
+
+    whole = produce(0, n_blocks, 0)
+    assert len(whole) == n_blocks * B - 63
+    plan = sharding.plan_generated_chain(n_blocks, world, B, 253)
+    parts = [produce(*p) for p in plan]
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape
+    assert rel_err(got, whole) <= 1e-6

@@ -30,6 +30,15 @@ def test_plan_chunks_cover_and_alignment():
     assert sharding.halo_range(5000, 127) == (4874, 126)
 
 
+def test_plan_generated_chain():
+    plan = sharding.plan_generated_chain(2101248, 8, 2044, 253)    # 2^32 samples of config 5
+    assert [p[1] for p in plan] == [262656] * 8 and plan[0] == (0, 262656, 0)
+    assert all(p[2] == 1 for p in plan[1:])                        # one 2044-sample packet covers 252 halo samples
+    assert sharding.plan_generated_chain(40, 2, 300, 1000)[1] == (20, 20, 4)
+    with pytest.raises(ValueError):
+        sharding.plan_generated_chain(4, 4, 256, 253)
+
+
 def _worker(rank, world, port, n, ntaps, cplx, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
