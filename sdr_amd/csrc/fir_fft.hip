@@ -260,9 +260,12 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
 
     // (channel, tile) of this workgroup's current and next tile, advanced without
     // 64-bit divisions; tt counts tiles of the channel from a.t_lo
+    // tile -> workgroup: contiguous runs (always with the spectrum cache; a.contig for
+    // the others) or grid-strided
+    const bool runs = CACHE || a.contig;
     struct Pos { long long ch, tt; };
     auto advance = [&](Pos p) {
-        p.tt += CACHE ? 1 : gridDim.x;
+        p.tt += runs ? 1 : gridDim.x;
         while (p.tt >= a.t_hi) { p.tt -= inner; ++p.ch; }
         return p;
     };
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
     long long left = 0;    // CACHE: tiles of this workgroup's run still to do
     long long prev_ch = -1; // CACHE: channel whose X_(b-1) sits in `prev`
     f2 prev[CACHE ? 16 : 1];
-    if (CACHE) {
+    if (runs) {
         const long long run = (total + gridDim.x - 1) / gridDim.x;
         const long long first = (long long)blockIdx.x * run;
         if (first >= total) return;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
         }
         // past the end the workgroup re-loads its own tile (harmless): keeps the body branch-free
         Pos nxt = advance(cur);
-        if (CACHE ? left <= 1 : nxt.ch >= a.channels) nxt = cur;
+        if (runs ? left <= 1 : nxt.ch >= a.channels) nxt = cur;
         const float* pn = in_ptr(nxt);
         f2 w[16];
         if (a.ablate & 1) {
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
     // memory operations from both of its predecessors (16 loads, then this tile's
     // stores): the waits at the top of the loop then cover the loads only.
     body();
-    while (CACHE ? left > 0 : cur.ch < a.channels) body();
+    while (runs ? left > 0 : cur.ch < a.channels) body();
 }
 
 // ---- edge tiles: the first tile(s) of every channel (they read the carried history)

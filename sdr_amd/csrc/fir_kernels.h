@@ -46,6 +46,7 @@ struct FftArgs {
     int hist_len;         // >= halo
     int ablate;           // diagnostics (SDR_AMD_FFT_ABLATE): 1 = skip the arithmetic (memory pattern only)
     int parts;            // filter partitions of 2048 taps (1 = plain overlap-save)
+    int contig;           // every workgroup walks a contiguous run of tiles instead of a grid-strided set
     long long t_lo, t_hi; // set by launch_fir_fft: tiles [t_lo, t_hi) of each channel go to the interior kernel
     GenSrc gen;           // gen.enabled: samples 0..n-1 are synthesised (real, one channel), `in` is unused
 };

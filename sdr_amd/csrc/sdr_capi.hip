@@ -275,6 +275,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.parts = f->fft_parts;
         fa.t_lo = fa.t_hi = 0;
         fa.ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
+        fa.contig = env_int("SDR_AMD_FFT_CONTIG", 0);
         SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur],
                                      f->d_hist[f->cur ^ 1], f->hist_len, f->w, f->channels, stream));
