@@ -6,13 +6,16 @@
 //       [[waveform=](cosine|sine|square|triangle|sawtooth)] sample_rate=HERTZ [amp=AMPLITUDE]
 //       [phi=PHASE] [mode=(real|complex)] [hilbert_taps=COUNT] [stream=ID]
 //
-// Runs until its output closes (SIGPIPE), like the reference.
-// Not implemented yet (reported as an error): unit=stream (frequency control input,
-// blocks/gen.cpp:61-81) and complex square/triangle/sawtooth (the reference's second
-// FIR call site, blocks/gen.cpp:231-260).
+// Runs until its output closes (SIGPIPE), like the reference; with unit=stream (FREQ =
+// the stream id of a frequency-control input on stdin, blocks/gen.cpp:61-81, 143-146,
+// 167-176) it runs until that input ends, retuning at packet boundaries.  Samples are
+// produced a few packets per GPU round trip, so a retune takes effect within that many
+// packets (the reference: within one).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
 #include <vector>
 
 #include "../include/sdr_amd.h"
@@ -35,6 +38,32 @@ float cycles_per_sample(int unit, float f, uint64_t sample_rate) {
     }
     if (unit == 3 || std::isnan(f) || std::isinf(f)) return 0.0f;
     return f;
+}
+
+// blocks/gen.cpp:61-81: the control input's Frequency / Wavelength / SampleCount packets
+// of stream `id`, first float of the payload, published for the generator loop
+std::atomic<float> freq_msg(0.0f);
+std::atomic<bool> source_end(false);
+std::atomic<bool> freq_msg_set(false);
+
+void freq_input(uint16_t id, uint64_t sample_rate) {
+    host::PacketReader source(0);
+    while (source.next()) {
+        const host::PacketHeader& h = source.header();
+        int unit = 3;
+        if (h.content == host::kFrequency) unit = 0;
+        else if (h.content == host::kWavelength) unit = 1;
+        else if (h.content == host::kSampleCount) unit = 2;
+        if (h.id == id && unit != 3 && h.size % sizeof(float) == 0 && h.size >= sizeof(float)) {
+            float f = 0.0f;
+            if (source.read_payload(&f, sizeof f) == sizeof f) {
+                freq_msg.store(cycles_per_sample(unit, f, sample_rate), std::memory_order_relaxed);
+                freq_msg_set.store(true, std::memory_order_release);
+            }
+        }
+    }
+    source_end.store(true, std::memory_order_relaxed);
+    freq_msg_set.store(true, std::memory_order_release);
 }
 } // namespace
 
@@ -63,16 +92,17 @@ int main(int argc, char* argv[]) {
             std::cerr << "error: gen: " << f << " is not a valid stream id" << std::endl;
             return -1;
         }
-        std::cerr << "error: gen: unit=stream (frequency control input) is not implemented in this build" << std::endl;
-        return -1;
     }
     if (!cli::valid_stream_id(id.as_uint())) {
         std::cerr << "error: gen: " << id.as_uint() << " is not a valid stream id" << std::endl;
         return -1;
     }
     const int kind = mode.as_choice();
-    if (kind == SDR_COMPLEX && waveform.as_choice() > SDR_WAVE_SINE) {
-        std::cerr << "error: gen: complex square/triangle/sawtooth are not implemented in this build" << std::endl;
+    const bool no_source = unit.as_choice() != 3;
+    const bool quadrature = kind == SDR_COMPLEX && waveform.as_choice() > SDR_WAVE_SINE;
+    if (quadrature && (hilbert_taps.as_uint() < 5 || hilbert_taps.as_uint() > (1u << 20))) {
+        // the reference's tap design is 0/0 below 5 taps (all-NaN quadrature)
+        std::cerr << "error: gen: hilbert_taps must be between 5 and 1048576" << std::endl;
         return -1;
     }
     if (sdr_device_count() < 1) {
@@ -97,13 +127,30 @@ int main(int argc, char* argv[]) {
         std::cerr << "error: gen: " << sdr_last_error() << std::endl;
         return -1;
     }
-    const size_t blocks_per_call = 512; // ~4 MiB per round trip
+    if (quadrature && sdr_gen_set_hilbert(g, hilbert_taps.as_uint(), no_source) != SDR_OK) {     // :138, 147-164
+        std::cerr << "error: gen: " << sdr_last_error() << std::endl;
+        return -1;
+    }
+    if (!no_source) {                                                         // :143-146
+        std::thread thr(freq_input, static_cast<uint16_t>(freq.as_float()), rate);
+        thr.detach();
+    }
+    float current = cps;
+    const size_t blocks_per_call = no_source ? 512 : 4; // ~4 MiB per round trip; short when retunable
     uint8_t* buf = static_cast<uint8_t*>(sdr_host_alloc(blocks_per_call * block * elt));
     if (!buf) {
         std::cerr << "error: gen: " << sdr_last_error() << std::endl;
         return -1;
     }
     for (;;) {
+        if (!no_source && freq_msg_set.exchange(false, std::memory_order_acq_rel)) {          // :167-176
+            if (source_end.load(std::memory_order_relaxed)) break;
+            const float msg = freq_msg.load(std::memory_order_relaxed);
+            if (msg != current) {
+                current = msg;
+                sdr_gen_set_frequency(g, current);
+            }
+        }
         if (sdr_gen_generate(g, blocks_per_call, buf) != SDR_OK) {
             std::cerr << "error: gen: " << sdr_last_error() << std::endl;
             return -1;
@@ -116,4 +163,7 @@ int main(int argc, char* argv[]) {
             }
         }
     }
+    sdr_gen_destroy(g);
+    sdr_host_free(buf);
+    return 0;
 }

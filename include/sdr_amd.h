@@ -147,10 +147,19 @@ size_t sdr_optimal_block_size(uint64_t element_size, uint64_t sample_rate);
 /* Replaces the set-up of the reference generator loop (blocks/gen.cpp:117-132):
  * amplitude A, frequency in cycles per sample (convert_freq,
  * include/sdr/options.hpp:120-141), initial phase in degrees, packets of
- * `block_size` samples.  SDR_REAL supports all five waveforms, SDR_COMPLEX
- * cosine and sine (A*cexp(j2pi(..)), blocks/gen.cpp:219-230). */
+ * `block_size` samples.  SDR_REAL: all five waveforms (blocks/gen.cpp:178-216);
+ * SDR_COMPLEX: cosine and sine as A*cexp(j2pi(..)) (:219-230), square / triangle /
+ * sawtooth as waveform + j*hilbert(waveform) (:231-260, see sdr_gen_set_hilbert). */
 int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, float amplitude, float cycles_per_sample,
                    float phase_degrees, size_t block_size, int device);
+/* Replaces the quadrature filter of the reference generator (blocks/gen.cpp:138
+ * `kfr::fir_state<RealSample> hilb(hilbert<RealSample>(hilbert_taps))` and the pre-roll
+ * at :147-164): complex square / triangle / sawtooth are the waveform plus +-j times its
+ * Hilbert transform from a real FIR of `hilbert_taps` taps (default 127); with
+ * preroll != 0 (default; the reference does it when there is no frequency-control input)
+ * (hilbert_taps-1)/2 samples run through the filter before the first block.  Call before
+ * the first generate. */
+int sdr_gen_set_hilbert(sdr_gen_t* g, size_t hilbert_taps, int preroll);
 /* New frequency from the next block on (the unit=stream control input,
  * blocks/gen.cpp:167-176). */
 int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample);

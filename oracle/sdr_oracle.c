@@ -247,6 +247,27 @@ static float fract_f(float x) { return x - floorf(x); } /* round.hpp:67 */
  * sinenorm(x) = fastsin(fract(x) * 2pi) (oscillators.hpp:48-57);
  * counter() is the in-block int index converted to float
  * (basic_expressions.hpp:112-116). */
+/* the five normalised oscillators of libs/kfr/dsp/oscillators.hpp at argument `arg`
+ * (cosine = sine: the caller adds the quarter cycle) */
+static float wave_value(int waveform, float arg) {
+    switch (waveform) {
+        case 2: /* squarenorm, oscillators.hpp:64-73 */
+            return fract_f(arg) < 0.5f ? 1.0f : -1.0f;
+        case 3: { /* trianglenorm, oscillators.hpp:107-116: 1 - |4 fract(x + 0.25) - 2|.
+                   * The reference's release build (-ffast-math) folds the +0.25 out of
+                   * the fraction: 4 (x - floor(x + 0.25)) - 1, which keeps the bits the
+                   * literal form loses when x + 0.25 is rounded (up to 1.3e-5 of RMS at
+                   * x ~ 40); the golden packets pin this form. */
+            float fl = floorf(arg + 0.25f);
+            return 1.0f - fabsf(4.0f * (arg - fl) - 1.0f);
+        }
+        case 4: /* sawtoothnorm, oscillators.hpp:80-89: 1 - 2 fract(x) */
+            return 1.0f - 2.0f * fract_f(arg);
+        default: /* sinenorm, oscillators.hpp:48-57 */
+            return sdro_fastsin(fract_f(arg) * TWO_PI_F);
+    }
+}
+
 void sdro_gen_real(float* out, size_t blocks, size_t block_size, float amp,
                    float cps, float* phi_io, int waveform) {
     float phi = *phi_io;
@@ -255,27 +276,39 @@ void sdro_gen_real(float* out, size_t blocks, size_t block_size, float amp,
         float base = waveform == 0 ? phi + 0.25f : phi;
         for (size_t i = 0; i < block_size; ++i) {
             float arg = base + cps * (float)(int)i;
-            float w;
-            switch (waveform) {
-                case 2: /* squarenorm, libs/kfr/dsp/oscillators.hpp:64-73 */
-                    w = fract_f(arg) < 0.5f ? 1.0f : -1.0f;
-                    break;
-                case 3: { /* trianglenorm, oscillators.hpp:107-116: 1 - |4 fract(x + 0.25) - 2|.
-                           * The reference's release build (-ffast-math) folds the +0.25 out of
-                           * the fraction: 4 (x - floor(x + 0.25)) - 1, which keeps the bits the
-                           * literal form loses when x + 0.25 is rounded (up to 1.3e-5 of RMS at
-                           * x ~ 40); the golden packets pin this form. */
-                    float fl = floorf(arg + 0.25f);
-                    w = 1.0f - fabsf(4.0f * (arg - fl) - 1.0f);
-                    break;
-                }
-                case 4: /* sawtoothnorm, oscillators.hpp:80-89: 1 - 2 fract(x) */
-                    w = 1.0f - 2.0f * fract_f(arg);
-                    break;
-                default: /* sinenorm, oscillators.hpp:48-57 */
-                    w = sdro_fastsin(fract_f(arg) * TWO_PI_F);
-            }
-            out[b * block_size + i] = amp * w;
+            out[b * block_size + i] = amp * wave_value(waveform, arg);
+        }
+        phi = fract_f(phi + phi_incr);
+    }
+    *phi_io = phi;
+}
+
+/* blocks/gen.cpp:147-164: before the first block of a complex square / triangle /
+ * sawtooth stream without a frequency-control input, hilb_delay samples of the
+ * waveform run through the quadrature filter and are discarded. */
+void sdro_gen_quad_preroll(sdro_fir* hilb, size_t hilb_delay, float cps, float phi, int waveform) {
+    for (size_t i = 0; i < hilb_delay; ++i) {
+        float x = wave_value(waveform, phi + cps * (float)(int)i), y;
+        sdro_fir_process(hilb, &x, 1, &y);
+    }
+}
+
+/* blocks/gen.cpp:231-260: block = A*(wave(phi + cps*i) + (+-j)*fir(hilb, wave(phi +
+ * (cps*hilb_delay) + cps*i))), -j for a negative frequency; hilb = real FIR state with
+ * sdr::hilbert taps (:138), carried from block to block. */
+void sdro_gen_complex_quad(float* out, size_t blocks, size_t block_size, float amp, float cps,
+                           float* phi_io, int waveform, sdro_fir* hilb, size_t hilb_delay) {
+    float phi = *phi_io;
+    const float phi_incr = fract_f(cps * (float)block_size);
+    const float sign = cps < 0 ? -1.0f : 1.0f;
+    for (size_t b = 0; b < blocks; ++b) {
+        const float adv = phi + (cps * (float)hilb_delay);
+        for (size_t i = 0; i < block_size; ++i) {
+            float re = wave_value(waveform, phi + cps * (float)(int)i);
+            float x = wave_value(waveform, adv + cps * (float)(int)i), q;
+            sdro_fir_process(hilb, &x, 1, &q);
+            out[2 * (b * block_size + i)] = amp * re;
+            out[2 * (b * block_size + i) + 1] = amp * (sign * q);
         }
         phi = fract_f(phi + phi_incr);
     }

@@ -60,7 +60,8 @@ size_t sdro_optimal_block_size(uint64_t element_size, uint64_t sample_rate);
 /* kfr fastsin (libs/kfr/base/sin_cos.hpp:183-206), x in [0, 2pi). */
 float sdro_fastsin(float x);
 
-/* Real sine (waveform 1) / cosine (waveform 0) generator: writes `blocks`
+/* Real generator, waveform 0 cosine, 1 sine, 2 square, 3 triangle, 4 sawtooth
+ * (libs/kfr/dsp/oscillators.hpp:48-116): writes `blocks`
  * blocks of `block_size` samples; *phi is the running block phase (in/out).
  * cps = cycles per sample. */
 void sdro_gen_real(float* out, size_t blocks, size_t block_size, float amp,
@@ -69,6 +70,14 @@ void sdro_gen_real(float* out, size_t blocks, size_t block_size, float amp,
 /* Complex cosine (0) / sine (1): A*cexp(j2pi(phi [-0.25] + cps*i)). */
 void sdro_gen_complex(float* out, size_t blocks, size_t block_size, float amp,
                       float cps, float* phi, int waveform);
+
+/* Complex square (2) / triangle (3) / sawtooth (4): the waveform plus +-j times its
+ * Hilbert transform from a real FIR (blocks/gen.cpp:138, 147-164, 231-260).  `hilb` is
+ * a real sdro_fir made from sdro_hilbert_taps(hilbert_taps), hilb_delay =
+ * (hilbert_taps - 1) / 2; the pre-roll runs once before the first block. */
+void sdro_gen_quad_preroll(sdro_fir* hilb, size_t hilb_delay, float cps, float phi, int waveform);
+void sdro_gen_complex_quad(float* out, size_t blocks, size_t block_size, float amp, float cps,
+                           float* phi, int waveform, sdro_fir* hilb, size_t hilb_delay);
 
 /* ---- hilbert block (blocks/hilbert.cpp:29-99) over an in-memory packet
  *      stream.  Returns bytes written to out (capacity out_cap), or

@@ -54,6 +54,7 @@ def lib():
         L.sdr_chain_reset.argtypes = [vp]
         L.sdr_chain_seek.argtypes = [vp, sz]
         L.sdr_gen_advance.argtypes = [vp, sz]
+        L.sdr_gen_set_hilbert.argtypes = [vp, sz, C.c_int]
         L.sdr_chain_destroy.argtypes = [vp]
         L.sdr_chain_destroy.restype = None
         L.sdr_chain_ntaps.argtypes = [vp]
@@ -318,6 +319,10 @@ class Gen:
 
     def generate_device(self, blocks, d_out, stream=None):
         _check(lib().sdr_gen_generate_device(self._h, blocks, d_out, C.c_void_p(stream or 0)))
+
+    def set_hilbert(self, hilbert_taps, preroll=True):
+        """Quadrature filter of complex square/triangle/sawtooth (gen.cpp:138, 147-164)."""
+        _check(lib().sdr_gen_set_hilbert(self._h, int(hilbert_taps), int(bool(preroll))))
 
     def advance(self, blocks):
         """Skip `blocks` packets (phase recurrence only)."""

@@ -16,5 +16,7 @@ struct GenArgs {
 };
 
 hipError_t launch_gen(const GenArgs& a, hipStream_t stream);
+// out[s] = {re[s], scale * q[s]}, s in [0, n)
+hipError_t launch_gen_interleave(float* out, const float* re, const float* q, float scale, long long n, hipStream_t stream);
 
 } // namespace sdr_amd

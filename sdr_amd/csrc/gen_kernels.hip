@@ -54,4 +54,18 @@ hipError_t launch_gen(const GenArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void gen_interleave(float2* __restrict__ out, const float* __restrict__ re,
+                                                      const float* __restrict__ q, float scale, long long n) {
+    for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < n; s += (long long)gridDim.x * 256)
+        out[s] = make_float2(re[s], __fmul_rn(scale, q[s]));
+}
+
+hipError_t launch_gen_interleave(float* out, const float* re, const float* q, float scale, long long n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    long long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gen_interleave, dim3((unsigned)grid), dim3(256), 0, stream, reinterpret_cast<float2*>(out), re, q, scale, n);
+    return hipGetLastError();
+}
+
 } // namespace sdr_amd

@@ -428,6 +428,15 @@ struct sdr_gen {
     int next_table = 0;
     float* d_out = nullptr; // staging for the host entry point
     size_t out_cap = 0;
+    // complex square / triangle / sawtooth (blocks/gen.cpp:138, 147-164, 231-260): the
+    // waveform plus +-j times its Hilbert transform from a real FIR
+    size_t hilbert_taps = 127;
+    bool preroll = true;      // hilb_delay samples through the filter before the first block
+    bool prerolled = false;
+    sdr_fir_t* quad = nullptr;
+    float* d_quad[3] = {nullptr, nullptr, nullptr}; // waveform, advanced waveform, filtered
+    size_t quad_cap = 0;                            // samples each
+    bool quadrature() const { return kind == SDR_COMPLEX && waveform > SDR_WAVE_SINE; }
 };
 
 static inline float fractf_host(float x) { return x - floorf(x); }
@@ -452,8 +461,6 @@ extern "C" int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, fl
     *out = nullptr;
     if (waveform < SDR_WAVE_COSINE || waveform > SDR_WAVE_SAWTOOTH) return fail(SDR_ERR_INVALID, "sdr_gen_create: unknown waveform");
     if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX) return fail(SDR_ERR_INVALID, "sdr_gen_create: bad sample_kind");
-    if (sample_kind == SDR_COMPLEX && waveform > SDR_WAVE_SINE)
-        return fail(SDR_ERR_INVALID, "sdr_gen_create: complex square/triangle/sawtooth are not implemented");
     if (block_size == 0 || block_size > (1u << 24)) return fail(SDR_ERR_INVALID, "sdr_gen_create: bad block_size");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -510,7 +517,10 @@ extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
 // `stream`.  The caller records t->free after the kernels that read the table.
 // fused: the table feeds a FIR kernel's generator source, which for cosine expects the
 // quarter-cycle advance (gen.cpp:184: phi + 0.25f, one fp32 addition per block) in the table.
-static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen::Table** out, bool fused = false) {
+// second: a second table follows at [cap, cap + blocks]: the same phases advanced by
+// `second_offset` (one fp32 addition per block: the quadrature path's phi + (cps*hilb_delay)).
+static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen::Table** out, bool fused = false,
+                          bool second = false, float second_offset = 0.0f) {
     sdr_gen::Table& t = g->table[g->next_table];
     g->next_table = (g->next_table + 1) % sdr_gen::kRing;
     SDR_HIP(hipEventSynchronize(t.free)); // the call that used this slot 4 calls ago
@@ -520,8 +530,8 @@ static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen
         t.h = t.d = nullptr;
         t.cap = 0;
         const size_t cap = std::max<size_t>(blocks + 1, 4096);
-        SDR_HIP(hipHostMalloc(&t.h, cap * sizeof(float), hipHostMallocDefault));
-        SDR_HIP(hipMalloc(&t.d, cap * sizeof(float)));
+        SDR_HIP(hipHostMalloc(&t.h, 2 * cap * sizeof(float), hipHostMallocDefault));
+        SDR_HIP(hipMalloc(&t.d, 2 * cap * sizeof(float)));
         t.cap = cap;
     }
     // sequential fp32 phase recurrence, one value per block (gen.cpp:185,192,227)
@@ -541,6 +551,10 @@ static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen
     }
     h[blocks] = phi;
     g->phi = phi;
+    if (second) {
+        for (size_t b = 0; b <= blocks; ++b) h[t.cap + b] = h[b] + second_offset;
+        SDR_HIP(hipMemcpyAsync(t.d + t.cap, t.h + t.cap, (blocks + 1) * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    }
     // upload on the generator's own stream: the host runs ahead of the GPU, so table k+1
     // crosses PCIe while the kernels of call k are still running on `stream`
     SDR_HIP(hipMemcpyAsync(t.d, t.h, (blocks + 1) * sizeof(float), hipMemcpyHostToDevice, g->stream));
@@ -550,8 +564,11 @@ static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen
     return SDR_OK;
 }
 
+static int gen_quadrature_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream);
+
 static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
     if (blocks == 0) return SDR_OK;
+    if (g->quadrature()) return gen_quadrature_impl(g, blocks, d_out, stream);
     sdr_gen::Table* t = nullptr;
     int rc = gen_next_table(g, blocks, stream, &t);
     if (rc != SDR_OK) return rc;
@@ -566,6 +583,87 @@ static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t 
     a.complex_samples = g->kind == SDR_COMPLEX;
     SDR_HIP(launch_gen(a, stream));
     SDR_HIP(hipEventRecord(t->free, stream));
+    return SDR_OK;
+}
+
+// blocks/gen.cpp:231-260.  Per block k, in-block index i:
+//   re = A * wave(phi_k + cps*i)
+//   im = A * (+-1) * fir(hilb, wave(phi_k + (cps*hilb_delay) + cps*i)),  - for cps < 0
+// hilb = real FIR with sdr::hilbert taps whose history runs on from block to block (and from
+// the pre-roll, :147-164).  Two generator launches, one pass of the FIR path, one interleave.
+static int gen_quadrature_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
+    const size_t n = blocks * g->block_size;
+    const size_t hd = (g->hilbert_taps - 1) / 2;
+    if (!g->quad) {
+        std::vector<float> h(g->hilbert_taps);
+        int rc = sdr_hilbert_taps(h.data(), h.size());
+        if (rc != SDR_OK) return rc;
+        rc = sdr_fir_create(&g->quad, h.data(), h.size(), SDR_REAL, 1, g->device);
+        if (rc != SDR_OK) return rc;
+    }
+    if (n > g->quad_cap || hd > g->quad_cap) {
+        SDR_HIP(hipStreamSynchronize(stream));
+        for (float*& p : g->d_quad) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+        g->quad_cap = 0;
+        const size_t cap = std::max(n, hd);
+        for (float*& p : g->d_quad) SDR_HIP(hipMalloc(&p, cap * sizeof(float)));
+        g->quad_cap = cap;
+    }
+    GenArgs a;
+    a.amp = 1.0f;
+    a.cps = g->cps;
+    a.waveform = g->waveform;
+    a.complex_samples = 0;
+    if (g->preroll && !g->prerolled && hd > 0) {
+        // one "block" of hilb_delay samples at the initial phase, filtered and discarded
+        const float save_phi = g->phi, save_incr = g->phi_incr;
+        sdr_gen::Table* t0 = nullptr;
+        g->phi_incr = 0.0f;
+        int rc = gen_next_table(g, 1, stream, &t0);
+        g->phi = save_phi;
+        g->phi_incr = save_incr;
+        if (rc != SDR_OK) return rc;
+        a.out = g->d_quad[1];
+        a.phi = t0->d;
+        a.blocks = 1;
+        a.block_size = (long long)hd;
+        SDR_HIP(launch_gen(a, stream));
+        SDR_HIP(hipEventRecord(t0->free, stream));
+        rc = sdr_fir_process_device(g->quad, g->d_quad[1], hd, hd, g->d_quad[2], hd, stream);
+        if (rc != SDR_OK) return rc;
+    }
+    g->prerolled = true;
+    sdr_gen::Table* t = nullptr;
+    const float adv = g->cps * (float)hd; // (cycles_per_sample*hilb_delay), gen.cpp:236
+    int rc = gen_next_table(g, blocks, stream, &t, false, true, adv);
+    if (rc != SDR_OK) return rc;
+    a.blocks = (long long)blocks;
+    a.block_size = (long long)g->block_size;
+    a.out = g->d_quad[0];
+    a.phi = t->d;
+    a.amp = g->amp;
+    SDR_HIP(launch_gen(a, stream));
+    a.out = g->d_quad[1];
+    a.phi = t->d + t->cap;
+    a.amp = 1.0f;
+    SDR_HIP(launch_gen(a, stream));
+    SDR_HIP(hipEventRecord(t->free, stream));
+    rc = sdr_fir_process_device(g->quad, g->d_quad[1], n, n, g->d_quad[2], n, stream);
+    if (rc != SDR_OK) return rc;
+    SDR_HIP(launch_gen_interleave(d_out, g->d_quad[0], g->d_quad[2], g->cps < 0 ? -g->amp : g->amp, (long long)n, stream));
+    return SDR_OK;
+}
+
+extern "C" int sdr_gen_set_hilbert(sdr_gen_t* g, size_t hilbert_taps, int preroll) {
+    clear_error();
+    if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: NULL handle");
+    if (g->prerolled || g->quad) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: the generator has already produced samples");
+    if (hilbert_taps < 5 || hilbert_taps > (1u << 20)) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: taps must be 5..2^20");
+    g->hilbert_taps = hilbert_taps;
+    g->preroll = preroll != 0;
     return SDR_OK;
 }
 
@@ -659,6 +757,9 @@ extern "C" void sdr_gen_destroy(sdr_gen_t* g) {
         if (t.ready) (void)hipEventDestroy(t.ready);
     }
     if (g->d_out) (void)hipFree(g->d_out);
+    for (float* p : g->d_quad)
+        if (p) (void)hipFree(p);
+    if (g->quad) sdr_fir_destroy(g->quad);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }

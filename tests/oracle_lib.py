@@ -46,6 +46,9 @@ def lib():
         L.sdro_fastsin.restype = C.c_float
         L.sdro_gen_real.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, C.c_float, fp, C.c_int]
         L.sdro_gen_complex.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, C.c_float, fp, C.c_int]
+        L.sdro_gen_quad_preroll.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_int]
+        L.sdro_gen_complex_quad.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_float, C.c_float, fp, C.c_int,
+                                            C.c_void_p, C.c_size_t]
         L.sdro_hilbert_block.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                          C.c_uint16, C.c_size_t, C.c_int, C.c_int]
         L.sdro_hilbert_block.restype = C.c_size_t
@@ -130,6 +133,18 @@ def gen_complex(blocks, block_size, amp, cps, phi, waveform):
     out = np.empty(blocks * block_size, np.complex64)
     p = C.c_float(phi)
     lib().sdro_gen_complex(_fp(out.view(np.float32)), blocks, block_size, amp, cps, C.byref(p), waveform)
+    return out, p.value
+
+
+def gen_complex_quad(blocks, block_size, amp, cps, phi, waveform, ntaps=127, preroll=True, acc64=False):
+    """Complex square/triangle/sawtooth: waveform + (+-j) * its Hilbert FIR (gen.cpp:231-260)."""
+    out = np.empty(blocks * block_size, np.complex64)
+    f = Fir(hilbert_taps(ntaps), False, acc64)
+    hd = (ntaps - 1) // 2
+    if preroll:
+        lib().sdro_gen_quad_preroll(f.h, hd, cps, phi, waveform)
+    p = C.c_float(phi)
+    lib().sdro_gen_complex_quad(_fp(out.view(np.float32)), blocks, block_size, amp, cps, C.byref(p), waveform, f.h, hd)
     return out, p.value
 
 

@@ -115,6 +115,25 @@ def test_gen_device_matches_oracle_recipe():
     assert np.max(np.abs(a - ref)) <= 3e-7
 
 
+@pytest.mark.parametrize("wf,amp,phase,freq,rate,ht,preroll", [
+    ("square", 1.0, 0.0, 100e3, 1000000, 127, True), ("triangle", 0.5, 30.0, 1e3, 48000, 31, True),
+    ("sawtooth", 1.0, 0.0, -7e3, 250000, 127, True), ("triangle", 1.0, 0.0, 3e3, 250000, 255, False)])
+def test_gen_complex_quadrature_waveforms(wf, amp, phase, freq, rate, ht, preroll):
+    """sdr_gen_*: complex square / triangle / sawtooth = waveform + (+-j) * Hilbert FIR of the
+    waveform advanced by the filter delay (blocks/gen.cpp:138-164, 231-260), phase and FIR
+    history carried across calls; against the oracle's restatement (pinned to the reference's
+    packets in tests/test_oracle_golden.py)."""
+    B = sdr_amd.optimal_block_size(8, rate)
+    cps = float(np.float32(freq) / np.float32(rate))
+    g = sdr_amd.Gen(wf, True, amp, cps, phase, B)
+    g.set_hilbert(ht, preroll)
+    got = np.concatenate([g.generate(2), g.generate(1), g.generate(9)])
+    phi0 = np.float32(phase) / np.float32(360.0)
+    ref, _ = O.gen_complex_quad(12, B, amp, cps, float(phi0), sdr_amd.WAVEFORMS[wf], ht, preroll, acc64=True)
+    rms = np.sqrt(np.mean(np.abs(ref.astype(np.complex128)) ** 2))
+    assert np.max(np.abs(got - ref)) <= TOL * rms
+
+
 def test_fused_gen_chain_config5_small():
     """Config C5 in small: generator -> hilbert(127, delay skip) -> lowpass(127) with the
     generated samples never leaving the GPU, chunk by chunk; compared with the oracle's

@@ -130,6 +130,31 @@ def test_gen_complex(golden_dir):
         assert np.max(np.abs(got - ref)) <= 5e-7, key
 
 
+def test_gen_complex_quadrature_waveforms(golden_dir):
+    """Complex square / triangle / sawtooth: the reference's second FIR call site
+    (blocks/gen.cpp:231-260): waveform + (+-j) * Hilbert FIR of the advanced waveform."""
+    g = np.load(os.path.join(golden_dir, "gen.npz"))
+    cases = [("complex_square_100k_1M", 1.0, 100e3, 1000000, 0.0, 2, 127),
+             ("complex_triangle_1k_48000_amp05_phi30_taps31", 0.5, 1e3, 48000, 30.0, 3, 31),
+             ("complex_sawtooth_neg7k_250k", 1.0, -7e3, 250000, 0.0, 4, 127)]
+    for key, amp, freq, sr, phase, wf, ht in cases:
+        pk = _gen_payloads(g[key])
+        B = O.optimal_block_size(8, sr)
+        full = [p for p in pk if len(p[4]) == p[2]]
+        assert len(full) >= 2 and all(p[1] == O.COMPLEX_SIGNAL and p[2] == 8 * B for p in full)
+        ref = np.concatenate([np.frombuffer(p[4], np.complex64) for p in full])
+        cps = np.float32(np.float32(freq) / np.float32(sr))
+        phi0 = np.float32(phase) / np.float32(360.0)
+        phi0 = np.float32(phi0 - np.floor(phi0))
+        got, _ = O.gen_complex_quad(len(full), B, amp, float(cps), float(phi0), wf, ht)
+        rms = np.sqrt(np.mean(np.abs(ref.astype(np.complex128)) ** 2))
+        bad = np.abs(got - ref) > 2e-6 * rms
+        # a square wave's switching instants can move by one sample where fract(arg) sits
+        # within an ulp of 0 or 0.5 (-ffast-math contraction in the reference build); such a
+        # flip changes that sample by 2A and the quadrature FIR output around it
+        assert np.count_nonzero(bad) <= (4 * ht if wf == 2 else 0), (key, int(np.count_nonzero(bad)), float(np.abs(got - ref).max() / rms))
+
+
 HILBERT_CASES = {
     "real_127": dict(), "complex_127": dict(), "real_128": dict(taps=128),
     "real_255_nodelay": dict(taps=255, delay=False), "complex_31_stream3": dict(stream_id=3, taps=31),
