@@ -7,6 +7,14 @@
 
 namespace host {
 
+const std::vector<std::pair<std::string, int>>& content_choices() {
+    static const std::vector<std::pair<std::string, int>> k = {
+        {"binary", kBinary}, {"string", kString}, {"time", kTime}, {"frequency", kFrequency},
+        {"wavelength", kWavelength}, {"sample_count", kSampleCount}, {"signal", kSignal},
+        {"complex_signal", kComplexSignal}, {"spectrum", kSpectrum}, {"complex_spectrum", kComplexSpectrum}};
+    return k;
+}
+
 size_t read_full(int fd, void* dst, size_t size) {
     uint8_t* p = static_cast<uint8_t*>(dst);
     size_t got = 0;

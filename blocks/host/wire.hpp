@@ -13,6 +13,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <string>
+#include <utility>
 #include <vector>
 
 namespace host {
@@ -21,6 +23,9 @@ enum Content : uint16_t {
     kBinary = 0, kString, kTime, kFrequency, kWavelength, kSampleCount,
     kSignal, kComplexSignal, kSpectrum, kComplexSpectrum, kContentCount
 };
+
+// content-type names of the reference's command lines (include/sdr/options.hpp:220-232)
+const std::vector<std::pair<std::string, int>>& content_choices();
 
 struct PacketHeader {
     uint16_t id;

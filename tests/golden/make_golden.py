@@ -185,6 +185,57 @@ fir_case("bandpass4095_real", "bandpass", 4095, 0.1, 0.2, False, 8192, 2044)
 fir_case("bandpass255_complex", "bandpass", 255, 0.05, 0.15, True, 2048, 100)
 save("fir.npz", **fir)
 
+# ---- (vi) host-only blocks: wrap, unwrap, inspect, throttle -----------------------
+def run_file(argv, data):
+    """stdin = a regular (seekable) file"""
+    path = "/tmp/_golden_stdin.bin"
+    with open(path, "wb") as f:
+        f.write(data)
+    with open(path, "rb") as f:
+        p = subprocess.run([os.path.join(REF, argv[0])] + argv[1:], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.stdout, p.stderr, p.returncode
+
+
+util, util_txt = {}, {}
+urng = np.random.default_rng(0x0B10C5)
+raw = urng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+util["raw"] = u8(raw)
+wrap_cases = {
+    "wrap_file_count": (["signal", "3", "element_size=4", "element_count=1000", "sample_rate=1M"], raw[:10000], True),
+    "wrap_pipe_count": (["signal", "3", "element_size=4", "element_count=1000", "sample_rate=1M"], raw[:10000], False),
+    "wrap_pipe_exact": (["signal", "3", "element_size=4", "element_count=1000", "sample_rate=1M"], raw[:8000], False),
+    "wrap_file_exact": (["signal", "3", "element_size=4", "element_count=1000", "sample_rate=1M"], raw[:8000], True),
+    "wrap_file_optimal": (["complex_signal", "element_size=8", "sample_rate=48000"], raw, True),
+    "wrap_file_duration": (["element_size=4", "duration=1000000", "sample_rate=1M"], raw[:10000], True),
+    "wrap_file_norate": (["string", "65535", "element_size=1"], raw[:20000], True),
+}
+for k, (args, data, seekable) in wrap_cases.items():
+    out, err, rc = (run_file if seekable else run)(["wrap"] + args, data)
+    util[k] = u8(out)
+    util_txt[k] = {"argv": args, "input_bytes": len(data), "seekable": seekable, "stderr": err.decode(), "rc": rc}
+pstream = b"".join(pkt(pid, c, raw[1000 * i: 1000 * i + n], d) for i, (pid, c, n, d) in enumerate(
+    [(0, 6, 400, 1000), (1, 7, 800, 2000), (2, 0, 13, 0), (1, 6, 0, 5), (0, 1, 7, 3000), (1, 7, 160, 4000)]))
+util["pstream"] = u8(pstream)
+for k, argv in {"unwrap_all": ["unwrap"], "unwrap_1": ["unwrap", "1"], "unwrap_7": ["unwrap", "stream=7"],
+                "inspect_all": ["inspect"], "inspect_1": ["inspect", "1"], "inspect_1_pass": ["inspect", "1", "pass"],
+                "inspect_1_pass_all": ["inspect", "1", "pass_all"], "inspect_all_pass_all": ["inspect", "pass_all=true"],
+                "throttle_all": ["throttle"], "throttle_1": ["throttle", "1"]}.items():
+    out, err, rc = run(argv, pstream)
+    util[k] = u8(out)
+    util_txt[k] = {"argv": argv, "stderr": err.decode(), "rc": rc}
+for k, argv in {"wrap_help": ["wrap", "help"], "unwrap_help": ["unwrap", "help"], "inspect_help": ["inspect", "help"],
+                "throttle_help": ["throttle", "help"], "wrap_missing": ["wrap"], "wrap_zero_size": ["wrap", "element_size=0"],
+                "wrap_zero_count": ["wrap", "element_size=4", "element_count=0"],
+                "wrap_short_duration": ["wrap", "element_size=4", "duration=10", "sample_rate=1M"],
+                "wrap_mismatch": ["wrap", "element_size=4", "element_count=10", "duration=7", "sample_rate=1M"],
+                "wrap_badid": ["wrap", "signal", "70000", "element_size=4"], "unwrap_badid": ["unwrap", "70000"]}.items():
+    out, err, rc = run(argv, b"")
+    util_txt[k] = {"argv": argv, "stderr": err.decode().replace(REF + "/", "./"), "rc": rc, "stdout_bytes": len(out)}
+save("utility.npz", **util)
+with open(os.path.join(HERE, "utility.json"), "w") as f:
+    json.dump(util_txt, f, indent=1)
+manifest["utility.npz / utility.json"] = "wrap / unwrap / inspect / throttle of the reference on the inputs stored beside the outputs (argv in utility.json)"
+
 with open(os.path.join(HERE, "manifest.json"), "w") as f:
     json.dump(manifest, f, indent=1)
 print("golden fixtures written:", sorted(os.listdir(HERE)))
