@@ -107,7 +107,7 @@ def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
                     chain.generate_device(gen, blocks_per_chunk, y.data_ptr() + 4 * i * chunk, stream=stream)
         bytes_per_step = nchunks * chunk * 4
         units = nchunks * chunk
-    name = "sdr_chain(253 fused taps) -> fir_fft4096_interior<REAL%s>" % (
+    name = "sdr_chain(253 fused taps) -> fir_fft4096<REAL%s>" % (
         ", GEN" if args.workload == "c5" and not args.unfused else "")
     return step, units, bytes_per_step, name, 253, desc
 

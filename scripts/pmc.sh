@@ -19,7 +19,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "interior" in row["Kernel_Name"]:
+        if "fir_fft4096" in row["Kernel_Name"] or "fir_direct" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k][1:] or acc[k]

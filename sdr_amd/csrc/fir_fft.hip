@@ -130,18 +130,33 @@ __device__ __forceinline__ f2 unit_root(int m, int M) { // exp(-2 pi i m / M)
 //   TA[k] = W_4096^(tid k), TB[k] = W_256^((tid&15) k), H[k2] = spectrum/N of bin
 //   (tid>>4) + 16 (tid&15) + 256 k2.
 // TBL: the W_256 twiddles are read from a 256-entry LDS table instead of 30 VGPRs.
-template <bool TBL>
+// TAL: the W_4096 twiddles too, from a lane-private LDS column ([k][tid], 30 KB per
+// workgroup): for the variants that run two workgroups per CU and need the registers.
+template <bool TBL, bool TAL = false>
 struct LaneConstsT {
-    f2 TA[16], TB[TBL ? 1 : 16], H[16];
+    f2 TA[TAL ? 1 : 16], TB[TBL ? 1 : 16], H[16];
     const f2* tb_lds;
+    const f2* ta_lds;
     __device__ __forceinline__ f2 tb(int k) const {
         if constexpr (TBL) return tb_lds[16 * k];
         else return TB[k];
     }
+    __device__ __forceinline__ f2 ta(int k) const {
+        if constexpr (TAL) return ta_lds[256 * k];
+        else return TA[k];
+    }
+    // table: 256 entries (TBL) followed by 16 x 256 entries (TAL)
     __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum, f2* table = nullptr) {
-        tb_lds = nullptr;
+        tb_lds = ta_lds = nullptr;
+        if constexpr (TAL) {
+            f2* col = table + 256 + tid;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) TA[k] = unit_root((tid * k) & 4095, 4096);
+            for (int k = 1; k < 16; ++k) col[256 * k] = unit_root((tid * k) & 4095, 4096);
+            ta_lds = col;
+        } else {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) TA[k] = unit_root((tid * k) & 4095, 4096);
+        }
         if constexpr (TBL) {
             // table[16 k + n] = W_256^(n k); a lane reads column n = tid & 15 (broadcast within 16-lane groups)
             table[tid] = unit_root(((tid & 15) * (tid >> 4)) & 255, 256);
@@ -169,7 +184,7 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
     dft16<false>(v);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.TA[k]);
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.ta(k));
     __syncthreads(); // everyone is done reading the rows (previous tile / previous pass)
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[k * ROW + tid] = v[P16(k)];
@@ -217,13 +232,14 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = lds[k * ROW + tid];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.TA[k]);
+    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.ta(k));
     dft16<true>(w);
 }
 
 // Filter spectrum of partition p, bin (tid>>4) + 16 (tid&15) + 256 k2, from L2.
 __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int tid) {
-    return reinterpret_cast<const f2*>(hperm)[p * FFT_N + k2 * 256 + tid];
+    // wave-uniform base + 32-bit lane offset: one VGPR of addressing for all 16 loads
+    return (reinterpret_cast<const f2*>(hperm) + (p * FFT_N + k2 * 256))[(unsigned)tid];
 }
 
 // ---- interior tiles: straight-line, software-pipelined -----------------------------
@@ -243,15 +259,14 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // GEN (real signals): the input is synthesised in registers by the reference
 // generator's recipe (gen_device.h) instead of being loaded -- the fused
 // gen -> hilbert -> FIR chain writes 4 bytes per sample and reads none.
+// Workgroup `bid` of `nblk` interior workgroups.
 template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE, bool GEN>
-__global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_interior(FftArgs a) {
+__device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const LaneConstsT<TBL, false>& c, const int bid,
+                                               const int nblk) {
     static_assert(!LONG || HB == 8, "partitioned mode uses hop 2048");
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
     static_assert(!GEN || REAL, "the generator source produces real samples");
-    __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     const int tid = threadIdx.x;
-    LaneConstsT<TBL> c;
-    c.init(tid, a.hperm, !LONG, TBL ? lds + 16 * ROW : nullptr);
     constexpr int W = REAL ? 1 : 2;
     constexpr long long L = FFT_N - 256 * HB;
     constexpr long long per_tile = REAL ? 2 * L : L;
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
     const bool runs = CACHE || a.contig;
     struct Pos { long long ch, tt; };
     auto advance = [&](Pos p) {
-        p.tt += runs ? 1 : gridDim.x;
+        p.tt += runs ? 1 : nblk;
         while (p.tt >= a.t_hi) { p.tt -= inner; ++p.ch; }
         return p;
     };
@@ -359,20 +374,20 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
         }
     };
 
-    if (inner <= 0 || (long long)blockIdx.x >= total) return;
+    if (inner <= 0 || (long long)bid >= total) return;
     Pos cur{0, 0};
     long long left = 0;    // CACHE: tiles of this workgroup's run still to do
     long long prev_ch = -1; // CACHE: channel whose X_(b-1) sits in `prev`
     f2 prev[CACHE ? 16 : 1];
     if (runs) {
-        const long long run = (total + gridDim.x - 1) / gridDim.x;
-        const long long first = (long long)blockIdx.x * run;
+        const long long run = (total + nblk - 1) / nblk;
+        const long long first = (long long)bid * run;
         if (first >= total) return;
         left = total - first < run ? total - first : run;
         cur.ch = first / inner;
         cur.tt = a.t_lo + (first - cur.ch * inner);
     } else {
-        cur.tt = a.t_lo + blockIdx.x;
+        cur.tt = a.t_lo + bid;
         while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
     }
     f2 nx[GEN ? 1 : 16]; // the next tile's points, loaded one tile ahead (nothing to prefetch with GEN)
@@ -413,7 +428,8 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
                     w[k] += cmul(prev[CACHE ? k : 0], spectrum(a.hperm, 1, k, tid));
                     prev[CACHE ? k : 0] = v[P16(k)];
                 }
-            } else if (LONG) {
+            }
+            if (LONG && !CACHE) {
                 for (int p = 1; p < a.parts; ++p) {
                     fetch(cur, (long long)p * 2048, v); // window b-p (L2 resident)
                     forward_tile(v, lds, tid, c, [] {});
@@ -450,24 +466,22 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096_inter
 
 // ---- edge tiles: the first tile(s) of every channel (they read the carried history)
 // and the tiles from the last full one on (partial outputs); also every tile of a
-// short call.  Bounds-checked, runtime halo / parts, no pipelining.
-template <bool REAL, bool GEN>
-__global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
+// short call.  Bounds-checked, runtime halo / parts, no pipelining.  Workgroup `bid` of
+// `nblk` edge workgroups.
+template <bool REAL, bool GEN, class Consts>
+__device__ __forceinline__ void edge_tiles(const FftArgs& a, f2* lds, const Consts& c, const int bid, const int nblk) {
     static_assert(!GEN || REAL, "the generator source produces real samples");
-    __shared__ __align__(16) f2 lds[16 * ROW];
     const int tid = threadIdx.x;
-    LaneConstsT<false> c;
-    c.init(tid, a.hperm, false);
     constexpr int W = REAL ? 1 : 2;
     const int halo = a.halo;
     const long long L = FFT_N - halo;
     const long long per_tile = REAL ? 2 * L : L;
     const long long tiles_per_ch = (a.n + per_tile - 1) / per_tile;
-    const long long skipped = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0; // handled by the interior kernel
+    const long long skipped = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0; // handled by the interior workgroups
     const long long edge_per_ch = tiles_per_ch - skipped;
     const long long total = edge_per_ch * a.channels;
 
-    for (long long e = blockIdx.x; e < total; e += gridDim.x) {
+    for (long long e = bid; e < total; e += nblk) {
         const long long ch = e / edge_per_ch;
         long long tt = e - ch * edge_per_ch;
         if (skipped && tt >= a.t_lo) tt += skipped;
@@ -515,43 +529,92 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_edge(FftArgs a) {
     }
 }
 
+// ---- history carry: after the call the other history buffer holds the last hist_len
+// samples of the virtual stream (old history | this call's input or synthesised samples).
+// Reads only what the call's other workgroups read; writes a buffer none of them touches.
+template <bool GEN>
+__device__ __forceinline__ void carry_history(const FftArgs& a, const int w, const int bid, const int nblk) {
+    const long long total = (long long)a.hist_len * w * a.channels;
+    for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
+        const long long ch = i / (a.hist_len * w);
+        const int r = (int)(i - ch * (a.hist_len * w));
+        const int s = r / w, k = r - s * w;
+        const long long m = a.n - a.hist_len + s;
+        float v;
+        if (m < 0) v = a.hist[(ch * a.hist_len + (a.hist_len + m)) * w + k];
+        else if constexpr (GEN) v = gen_src_at(a.gen, m);
+        else v = a.in[(ch * a.in_stride + m) * w + k];
+        a.new_hist[i] = v;
+    }
+}
+
+// ---- one launch per call.  The first a.grid_carry workgroups carry the history, the
+// next a.grid_edge take the edge tiles, the rest are the persistent interior
+// workgroups: the few slow, bounds-checked tiles start first and overlap the bulk
+// instead of trailing it as separate launches.
+template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE, bool GEN>
+__global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftArgs a) {
+    __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
+    int bid = blockIdx.x;
+    LaneConstsT<TBL, false> c;
+    // (the partitioned variants keep their short work in a launch of its own,
+    // fir_fft4096_short: sharing a kernel with it costs their main loop 20 %)
+    if constexpr (!LONG) {
+        if (bid < a.grid_carry) {
+            carry_history<GEN>(a, REAL ? 1 : 2, bid, a.grid_carry);
+            return;
+        }
+        bid -= a.grid_carry;
+        if (bid < a.grid_edge) {
+            c.init(threadIdx.x, a.hperm, false, TBL ? lds + 16 * ROW : nullptr);
+            edge_tiles<REAL, GEN>(a, lds, c, bid, a.grid_edge);
+            return;
+        }
+        bid -= a.grid_edge;
+    }
+    c.init(threadIdx.x, a.hperm, !LONG, TBL ? lds + 16 * ROW : nullptr);
+    interior_tiles<REAL, HB, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
+                                                    LONG ? (int)gridDim.x : (int)gridDim.x - a.grid_carry - a.grid_edge);
+}
+
+// carry + edge workgroups alone (partitioned filters; calls without interior tiles)
 template <bool REAL, bool GEN>
-static hipError_t launch_interior(const FftArgs& a, long long grid, hipStream_t stream) {
-    const dim3 g((unsigned)grid), b(256);
-    if (a.parts == 2 && !(a.ablate & 4)) {
-        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, true, true, GEN>), g, b, 0, stream, a);
-        return hipGetLastError();
+__global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
+    __shared__ __align__(16) f2 lds[16 * ROW + 256];
+    int bid = blockIdx.x;
+    if (bid < a.grid_carry) {
+        carry_history<GEN>(a, REAL ? 1 : 2, bid, a.grid_carry);
+        return;
     }
+    bid -= a.grid_carry;
+    LaneConstsT<true> c;
+    c.init(threadIdx.x, a.hperm, false, lds + 16 * ROW);
+    edge_tiles<REAL, GEN>(a, lds, c, bid, a.grid_edge);
+}
+
+template <bool REAL, bool GEN>
+static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t stream) {
+    const dim3 b(256);
+    const int n_short = a.grid_carry + a.grid_edge;
     if (a.parts > 1) {
-        hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, true, false, false, GEN>), g, b, 0, stream, a);
+        const dim3 g((unsigned)grid_int);
+        if (grid_int > 0) {
+            if (a.parts == 2 && !(a.ablate & 4)) hipLaunchKernelGGL((fir_fft4096<REAL, 8, true, true, true, GEN>), g, b, 0, stream, a);
+            else hipLaunchKernelGGL((fir_fft4096<REAL, 8, true, false, false, GEN>), g, b, 0, stream, a);
+        }
+        if (n_short > 0) hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN>), dim3((unsigned)n_short), b, 0, stream, a);
         return hipGetLastError();
     }
+    const dim3 g((unsigned)(grid_int + n_short));
     // W_256 twiddles from the LDS table: 161 VGPRs, three workgroups per CU (+3 % over
     // the all-register build at two per CU, profiles/r01_fft_variants.txt)
     switch (a.halo / 256) {
-        case 1: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 1, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 2, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 4, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((fir_fft4096_interior<REAL, 8, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fir_fft4096<REAL, 1, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096<REAL, 2, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096<REAL, 4, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096<REAL, 8, false, true, false, GEN>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
-}
-
-// History after a synthesised call: virtual samples n-hist_len .. n-1 (old history where < 0).
-__global__ void fir_carry_history_gen(GenSrc g, long long n, const float* __restrict__ old_hist,
-                                      float* __restrict__ new_hist, int hist_len) {
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < hist_len; s += gridDim.x * blockDim.x) {
-        const long long m = n - hist_len + s;
-        new_hist[s] = m >= 0 ? gen_src_at(g, m) : old_hist[hist_len + m];
-    }
-}
-
-hipError_t launch_carry_history_gen(const GenSrc& g, long long n, const float* old_hist, float* new_hist,
-                                    int hist_len, hipStream_t stream) {
-    const int blocks = (hist_len + 255) / 256;
-    hipLaunchKernelGGL(fir_carry_history_gen, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, g, n, old_hist,
-                       new_hist, hist_len);
     return hipGetLastError();
 }
 
@@ -579,28 +642,22 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     a.t_hi = a.n / per_tile;
     const long long inner = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0;
     if (inner == 0) a.t_lo = a.t_hi = 0;
-    hipError_t e = hipSuccess;
+    // equal shares: with T interior tiles and at most G workgroups every workgroup walks
+    // ceil(T/G) tiles (or one fewer), instead of G workgroups of uneven load
+    long long grid_int = 0;
     if (inner > 0) {
-        // equal shares: with T tiles and at most G workgroups every workgroup walks
-        // ceil(T/G) tiles (or one fewer), instead of G workgroups of uneven load
         const long long total = inner * a.channels;
         const long long rounds = (total + grid_blocks - 1) / grid_blocks;
-        const long long grid = (total + rounds - 1) / rounds;
-        if (a.gen.enabled) e = launch_interior<true, true>(a, grid, stream);
-        else e = real ? launch_interior<true, false>(a, grid, stream) : launch_interior<false, false>(a, grid, stream);
-        if (e != hipSuccess) return e;
+        grid_int = (total + rounds - 1) / rounds;
     }
     const long long edge = (tiles_per_ch - inner) * a.channels;
-    if (edge > 0) {
-        long long grid = edge < grid_blocks ? edge : grid_blocks;
-        if (a.gen.enabled) hipLaunchKernelGGL((fir_fft4096_edge<true, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-        else if (real) hipLaunchKernelGGL((fir_fft4096_edge<true, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((fir_fft4096_edge<false, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-        e = hipGetLastError();
-    }
-    return e;
+    a.grid_edge = (int)(edge < grid_blocks ? edge : grid_blocks);
+    const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
+    a.grid_carry = a.new_hist ? (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64) : 0;
+    if (a.gen.enabled) return launch_tiles<true, true>(a, grid_int, stream);
+    return real ? launch_tiles<true, false>(a, grid_int, stream) : launch_tiles<false, false>(a, grid_int, stream);
 }
 
-const char* fir_fft_kernel_name(bool real) { return real ? "fir_fft4096_interior<REAL>" : "fir_fft4096_interior<COMPLEX>"; }
+const char* fir_fft_kernel_name(bool real) { return real ? "fir_fft4096<REAL>" : "fir_fft4096<COMPLEX>"; }
 
 } // namespace sdr_amd

@@ -47,12 +47,11 @@ struct FftArgs {
     int ablate;           // diagnostics (SDR_AMD_FFT_ABLATE): 1 = skip the arithmetic (memory pattern only)
     int parts;            // filter partitions of 2048 taps (1 = plain overlap-save)
     int contig;           // every workgroup walks a contiguous run of tiles instead of a grid-strided set
-    long long t_lo, t_hi; // set by launch_fir_fft: tiles [t_lo, t_hi) of each channel go to the interior kernel
+    float* new_hist;      // [channels][hist_len]: receives the history after this call (NULL: not carried)
+    long long t_lo, t_hi; // set by launch_fir_fft: tiles [t_lo, t_hi) of each channel are interior tiles
+    int grid_carry, grid_edge; // set by launch_fir_fft: leading workgroups that carry the history / take edge tiles
     GenSrc gen;           // gen.enabled: samples 0..n-1 are synthesised (real, one channel), `in` is unused
 };
-// after a call whose input was synthesised: the last hist_len samples into new_hist
-hipError_t launch_carry_history_gen(const GenSrc& g, long long n, const float* old_hist, float* new_hist,
-                                    int hist_len, hipStream_t stream);
 hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
 const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);

@@ -276,9 +276,8 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.t_lo = fa.t_hi = 0;
         fa.ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
         fa.contig = env_int("SDR_AMD_FFT_CONTIG", 0);
+        fa.new_hist = f->d_hist[f->cur ^ 1];
         SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
-        SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur],
-                                     f->d_hist[f->cur ^ 1], f->hist_len, f->w, f->channels, stream));
         f->cur ^= 1;
         return SDR_OK;
     }
@@ -707,8 +706,8 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.gen.cps = g->cps;
     fa.gen.waveform = g->waveform;
     fa.gen.enabled = 1;
+    fa.new_hist = f->d_hist[f->cur ^ 1];
     SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
-    SDR_HIP(launch_carry_history_gen(fa.gen, fa.n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1], f->hist_len, stream));
     f->cur ^= 1;
     SDR_HIP(hipEventRecord(t->free, stream));
     return SDR_OK;
