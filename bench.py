@@ -47,6 +47,9 @@ WORKLOADS = {
                False, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 27, 1),
     "c4": ("64 channels x 2^22 real samples, hilbert 127 taps (BASELINE configs[3] first stage)",
            False, lambda S: S.hilbert(127), 22, 64),
+    "lp31": ("31-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(31, 0.1), 28, 1),
+    "lp15": ("15-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(15, 0.1), 28, 1),
+    "lp63r": ("63-tap lowpass on 2^28 real samples, in-memory", False, lambda S: S.fir_lowpass(63, 0.1), 28, 1),
     "lp255": ("255-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(255, 0.1), 28, 1),
     # fused chains (sdr_chain_*): handled by bench_chain() below
     "c4chain": ("64 channels x 2^22 real samples, hilbert(127, delay skip) + lowpass(127) fused in one pass "

@@ -3,7 +3,7 @@
 IFS='|' read -ra ENVS <<< "$1"; shift
 for wl in "$@"; do
   for e in "${ENVS[@]}"; do
-    env $e timeout -k 10 120 python3 bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+    env $e timeout -k 10 120 python3 bench.py --workload $wl --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
