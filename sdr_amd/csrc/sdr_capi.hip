@@ -137,7 +137,9 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     // times 4096/(4096-halo).  SDR_AMD_FFT=0/1 forces the choice.
     int fft_halo = 0, fft_parts = 1;
     fir_fft_plan(ntaps, &fft_halo, &fft_parts);
-    bool use_fft = ntaps >= (stride == 2 ? 100u : 64u) && fft_parts <= 64;
+    // Measured crossover (profiles/r01_direct_vs_fft_crossover.txt): the direct form holds
+    // its memory-bound floor (5.7 TB/s) up to ~47 dense or ~95 Hilbert-structured taps.
+    bool use_fft = ntaps >= (stride == 2 ? 100u : 48u) && fft_parts <= 64;
     if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_parts <= 64;
 
     int R = env_int("SDR_AMD_R", 8);
