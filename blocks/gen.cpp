@@ -135,6 +135,7 @@ int main(int argc, char* argv[]) {
         std::thread thr(freq_input, static_cast<uint16_t>(freq.as_float()), rate);
         thr.detach();
     }
+    host::widen_pipe(1);
     float current = cps;
     const size_t blocks_per_call = no_source ? 512 : 4; // ~4 MiB per round trip; short when retunable
     uint8_t* buf = static_cast<uint8_t*>(sdr_host_alloc(blocks_per_call * block * elt));
@@ -155,12 +156,15 @@ int main(int argc, char* argv[]) {
             std::cerr << "error: gen: " << sdr_last_error() << std::endl;
             return -1;
         }
+        host::GatherWriter out(1);
         for (size_t b = 0; b < blocks_per_call; ++b) {
-            if (!host::write_full(1, &hdr, sizeof hdr) || !host::write_full(1, buf + b * block * elt, block * elt)) {
-                sdr_gen_destroy(g);
-                sdr_host_free(buf);
-                return 0; // output closed
-            }
+            out.add(&hdr, sizeof hdr);
+            out.add(buf + b * block * elt, block * elt);
+        }
+        if (!out.flush()) {
+            sdr_gen_destroy(g);
+            sdr_host_free(buf);
+            return 0; // output closed
         }
     }
     sdr_gen_destroy(g);

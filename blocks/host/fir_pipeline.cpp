@@ -122,6 +122,7 @@ int FirPipeline::finish(Batch* b) {
 
 void FirPipeline::writer_loop(int out_fd) {
     PacketWriter w(out_fd);
+    widen_pipe(out_fd);
     for (;;) {
         Batch* b;
         {
@@ -132,11 +133,16 @@ void FirPipeline::writer_loop(int out_fd) {
             ready_.pop_front();
         }
         const size_t elt = b->complex_samples ? 8 : 4;
+        // headers of the filtered packets are rewritten: they live here until the flush
+        std::vector<PacketHeader> hdrs;
+        hdrs.reserve(b->items.size());
+        std::vector<uint8_t> zeros;
+        GatherWriter out(out_fd);
         for (const Item& it : b->items) {
             if (!it.filtered) {
                 // forwarded untouched; a truncated payload stays truncated
-                (void)write_full(out_fd, &it.hdr, sizeof it.hdr);
-                (void)write_full(out_fd, b->raw.data() + it.offset, it.count);
+                out.add(&it.hdr, sizeof it.hdr);
+                out.add(b->raw.data() + it.offset, it.count);
                 continue;
             }
             // Group-delay compensation, per packet, with the reference's integer
@@ -153,18 +159,23 @@ void FirPipeline::writer_loop(int out_fd) {
             }
             if (n - skip) h.size = static_cast<uint32_t>((n - skip) * elt);
             const uint8_t* payload = reinterpret_cast<const uint8_t*>(b->out) + (it.offset + skip) * elt;
-            (void)write_full(out_fd, &h, sizeof h);
+            hdrs.push_back(h);
+            out.add(&hdrs.back(), sizeof h);
             if (n - skip) {
-                (void)write_full(out_fd, payload, (n - skip) * elt);
+                out.add(payload, (n - skip) * elt);
             } else if (h.size) {
                 // no whole sample arrived (size not a multiple of the sample size, or
                 // EOF right after the header): the reference sends the header with
                 // its size unchanged followed by unspecified bytes
                 // (include/sdr/stream.hpp:133-139); zeros keep the stream framed.
-                const std::vector<uint8_t> zeros(h.size, 0);
-                (void)write_full(out_fd, zeros.data(), zeros.size());
+                if (zeros.size() < h.size) {
+                    (void)out.flush(); // `zeros` may move
+                    zeros.assign(h.size, 0);
+                }
+                out.add(zeros.data(), h.size);
             }
         }
+        (void)out.flush();
         {
             std::lock_guard<std::mutex> lk(mu_);
             free_.push_back(b);
@@ -256,7 +267,7 @@ int FirPipeline::run(int in_fd, int out_fd) {
             cur->samples += got;
         }
         // nothing more to read right now: do not sit on a partial batch
-        if (!input_ready(in_fd))
+        if (!rd.input_pending())
             if ((rc = flush(true))) break;
     }
     if (!rc) rc = flush(true);

@@ -1,7 +1,10 @@
 #include "wire.hpp"
 
+#include <algorithm>
 #include <cerrno>
+#include <fcntl.h>
 #include <poll.h>
+#include <sys/uio.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -54,12 +57,52 @@ bool input_ready(int fd) {
     return r != 0; // data, hangup or error: a read will not block
 }
 
+// A pipe end asks for a 1 MiB kernel buffer (the default is 64 KiB): fewer wake-ups per
+// megabyte for both neighbours.  Best effort; not a FIFO or not permitted = no change.
+void widen_pipe(int fd) {
+#ifdef F_SETPIPE_SZ
+    struct stat st;
+    if (::fstat(fd, &st) == 0 && S_ISFIFO(st.st_mode)) (void)::fcntl(fd, F_SETPIPE_SZ, 1 << 20);
+#else
+    (void)fd;
+#endif
+}
+
+PacketReader::PacketReader(int fd) : fd_(fd), buf_(1u << 20) { widen_pipe(fd); }
+
+size_t PacketReader::fetch(void* dst, size_t bytes) {
+    uint8_t* p = static_cast<uint8_t*>(dst);
+    size_t got = 0;
+    while (got < bytes) {
+        if (pos_ < end_) {
+            const size_t take = std::min(bytes - got, end_ - pos_);
+            if (p) std::memcpy(p + got, buf_.data() + pos_, take);
+            pos_ += take;
+            got += take;
+            continue;
+        }
+        // buffer empty: a large remainder goes straight to its destination, anything
+        // else refills the buffer with whatever one read() returns
+        ssize_t r;
+        if (p && bytes - got >= buf_.size()) {
+            r = ::read(fd_, p + got, bytes - got);
+            if (r > 0) got += static_cast<size_t>(r);
+        } else {
+            r = ::read(fd_, buf_.data(), buf_.size());
+            if (r > 0) { pos_ = 0; end_ = static_cast<size_t>(r); }
+        }
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break;
+    }
+    return got;
+}
+
+bool PacketReader::input_pending() const { return pos_ < end_ || input_ready(fd_); }
+
 void PacketReader::skip_rest() {
-    uint8_t sink[4096];
-    while (!eof_ && consumed_ < hdr_.size) {
-        size_t want = hdr_.size - consumed_;
-        if (want > sizeof sink) want = sizeof sink;
-        size_t got = read_full(fd_, sink, want);
+    if (!eof_ && consumed_ < hdr_.size) {
+        const size_t want = hdr_.size - consumed_;
+        const size_t got = fetch(nullptr, want);
         consumed_ += got;
         if (got < want) eof_ = true;
     }
@@ -73,7 +116,7 @@ bool PacketReader::next() {
         return false;
     }
     PacketHeader h;
-    if (read_full(fd_, &h, sizeof h) < sizeof h) {
+    if (fetch(&h, sizeof h) < sizeof h) {
         hdr_ = PacketHeader{};
         eof_ = true;
         return false;
@@ -86,10 +129,46 @@ size_t PacketReader::read_payload(void* dst, size_t bytes) {
     size_t left = hdr_.size - consumed_;
     if (bytes > left) bytes = left;
     if (bytes == 0 || eof_) return 0;
-    size_t got = read_full(fd_, dst, bytes);
+    size_t got = fetch(dst, bytes);
     if (got < bytes) eof_ = true;
     consumed_ += got;
     return got;
+}
+
+void GatherWriter::add(const void* p, size_t n) {
+    if (n) parts_.emplace_back(p, n);
+    if (parts_.size() >= 1000) (void)flush();
+}
+
+bool GatherWriter::flush() {
+    bool ok = true;
+    size_t i = 0;
+    size_t done_in_first = 0; // bytes of parts_[i] already written
+    while (ok && i < parts_.size()) {
+        struct iovec iov[512];
+        int n = 0;
+        for (size_t j = i; j < parts_.size() && n < 512; ++j, ++n) {
+            const size_t off = j == i ? done_in_first : 0;
+            iov[n].iov_base = const_cast<uint8_t*>(static_cast<const uint8_t*>(parts_[j].first)) + off;
+            iov[n].iov_len = parts_[j].second - off;
+        }
+        ssize_t w = ::writev(fd_, iov, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            ok = false;
+            break;
+        }
+        size_t left = static_cast<size_t>(w);
+        while (i < parts_.size() && left >= parts_[i].second - done_in_first) {
+            left -= parts_[i].second - done_in_first;
+            done_in_first = 0;
+            ++i;
+        }
+        done_in_first += left;
+        if (w == 0) { ok = false; break; }
+    }
+    parts_.clear();
+    return ok;
 }
 
 void PacketWriter::send(const PacketHeader& hdr, const void* payload) {

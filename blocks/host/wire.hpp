@@ -39,6 +39,8 @@ static_assert(sizeof(PacketHeader) == 16, "wire header is 16 bytes");
 size_t read_full(int fd, void* dst, size_t size);
 // Writes everything or returns false on error.
 bool write_full(int fd, const void* src, size_t size);
+// Best effort: a 1 MiB kernel buffer for a pipe end (no effect on other descriptors).
+void widen_pipe(int fd);
 // True when a read on fd would not block right now (data or EOF pending).
 bool input_ready(int fd);
 
@@ -46,9 +48,13 @@ bool input_ready(int fd);
 // Source::next/recv/drop, lib/sdr/stream.cpp:121-249: unread payload of the
 // previous packet is discarded by next(); a short header is a clean EOF; a short
 // payload yields what arrived and ends the stream).
+// Reads are buffered: one read(2) fetches whatever the pipe holds (up to 1 MiB) and
+// headers and payloads are served from that buffer -- with ~8 KiB packets a system call
+// per header and per payload is what bounds a block's throughput otherwise.  A refill
+// never waits for more than the first byte, so an interactive pipe sees no added latency.
 class PacketReader {
 public:
-    explicit PacketReader(int fd = 0) : fd_(fd) {}
+    explicit PacketReader(int fd = 0);
     // Advance to the next packet header.  False at end of stream.
     bool next();
     const PacketHeader& header() const { return hdr_; }
@@ -57,13 +63,33 @@ public:
     size_t remaining() const { return hdr_.size - consumed_; }
     bool eof() const { return eof_; }
     int fd() const { return fd_; }
+    // True when the next read would not block: bytes already buffered, or the
+    // descriptor readable (data or end of input).
+    bool input_pending() const;
 
 private:
+    size_t fetch(void* dst, size_t bytes); // from the buffer, then the descriptor; short only at end of input
     void skip_rest();
     int fd_;
     PacketHeader hdr_{};
     size_t consumed_ = 0;
     bool eof_ = false;
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0, end_ = 0;
+};
+
+// Gathers many small writes (header, payload, header, payload, ...) into few writev(2)
+// calls.  The memory handed to add() must stay valid until flush().
+class GatherWriter {
+public:
+    explicit GatherWriter(int fd) : fd_(fd) {}
+    size_t pending() const { return parts_.size(); }
+    void add(const void* p, size_t n);
+    bool flush(); // false on a write error (the rest is dropped)
+
+private:
+    int fd_;
+    std::vector<std::pair<const void*, size_t>> parts_;
 };
 
 class PacketWriter {
