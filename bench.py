@@ -190,11 +190,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libsdr_amd has no CPU path")
+    # one rank per GPU; SDR_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with
+    # fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("SDR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     desc, cplx, mk_taps, log2n, channels = WORKLOADS[args.workload]
     if mk_taps is None:
@@ -254,7 +262,7 @@ def run_and_report(args, torch, dist, rank, world, dev, step, units, step_bytes,
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # device time per step: HIP events on the launch stream (torch's current stream is

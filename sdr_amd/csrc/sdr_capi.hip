@@ -75,6 +75,7 @@ struct sdr_fir {
     int fft_halo = 0;
     int fft_parts = 1;
     int fft_grid = 0;
+    int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
     float* d_hperm = nullptr;
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
@@ -227,6 +228,8 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 6);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
         f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", f->fft_grid));
+        f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
+        f->fft_contig = env_int("SDR_AMD_FFT_CONTIG", 0);
     }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
@@ -276,8 +279,8 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.hist_len = f->hist_len;
         fa.parts = f->fft_parts;
         fa.t_lo = fa.t_hi = 0;
-        fa.ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
-        fa.contig = env_int("SDR_AMD_FFT_CONTIG", 0);
+        fa.ablate = f->fft_ablate;
+        fa.contig = f->fft_contig;
         fa.new_hist = f->d_hist[f->cur ^ 1];
         SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         f->cur ^= 1;
