@@ -177,15 +177,21 @@ struct LaneConstsT {
 // Forward transform of one tile: v[n2] = x[256 n2 + tid] in, X[(tid>>4) + 16 (tid&15)
 // + 256 k2] left at v[P16(k2)].  `after_points_left` runs once the input points have
 // left the registers (the slot where the next tile's loads are issued).
+// `after_forward`: the previous use of the exchange buffer was another forward transform,
+// whose last reads (stage C) cover whole rows -- columns of other waves included -- so
+// everyone must be done before this one writes.  After an INVERSE transform no barrier is
+// needed here: past its block barrier every wave only reads its own columns (stage A'),
+// and the writes below touch only the writer's own columns.
 template <class Consts, class Hook>
-__device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const Consts& c, Hook&& after_points_left) {
+__device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const Consts& c, Hook&& after_points_left,
+                                             bool after_forward = false) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
     // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
     dft16<false>(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.ta(k));
-    __syncthreads(); // everyone is done reading the rows (previous tile / previous pass)
+    if (after_forward) __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[k * ROW + tid] = v[P16(k)];
     after_points_left();
@@ -395,6 +401,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
 
     auto body = [&]() {
         f2 v[16];
+        bool after_forward = false;
         if (CACHE && prev_ch != cur.ch) {
             // start of a run or of a channel: transform window b-1 once
             fetch(cur, 2048, v);
@@ -402,6 +409,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
 #pragma unroll
             for (int k = 0; k < 16; ++k) prev[CACHE ? k : 0] = v[P16(k)];
             prev_ch = cur.ch;
+            after_forward = true;
         }
         if constexpr (GEN) {
             fetch(cur, 0, v);
@@ -419,7 +427,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[P16(k)] = v[k];
         } else {
-            forward_tile(v, lds, tid, c, [&] { if constexpr (!GEN) load(pn, nx); });
+            forward_tile(v, lds, tid, c, [&] { if constexpr (!GEN) load(pn, nx); }, after_forward);
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
             if (CACHE) {
@@ -432,7 +440,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
             if (LONG && !CACHE) {
                 for (int p = 1; p < a.parts; ++p) {
                     fetch(cur, (long long)p * 2048, v); // window b-p (L2 resident)
-                    forward_tile(v, lds, tid, c, [] {});
+                    forward_tile(v, lds, tid, c, [] {}, true);
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
                         const f2 t = cmul(v[P16(k)], spectrum(a.hperm, p, k, tid));
@@ -505,7 +513,7 @@ __device__ __forceinline__ void edge_tiles(const FftArgs& a, f2* lds, const Cons
                 if (REAL) v[n2] = f2{sample(m, 0), sample(m + L, 0)};
                 else v[n2] = f2{sample(m, 0), sample(m, 1)};
             }
-            forward_tile(v, lds, tid, c, [] {});
+            forward_tile(v, lds, tid, c, [] {}, p > 0);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const f2 t = cmul(v[P16(k)], spectrum(a.hperm, p, k, tid));
