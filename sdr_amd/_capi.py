@@ -18,7 +18,8 @@ class SdrError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libsdr_amd.so")
+    # SDR_AMD_LIB: an alternative build of the library (kernel experiments)
+    return os.environ.get("SDR_AMD_LIB") or os.path.join(_HERE, "lib", "libsdr_amd.so")
 
 
 def lib():

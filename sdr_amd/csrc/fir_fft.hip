@@ -35,9 +35,34 @@
 
 #include "fir_kernels.h"
 
+// cache policy of the streaming loads / stores (experiments: -DSDR_LD_NT=0 / -DSDR_ST_NT=0)
+#ifndef SDR_LD_NT
+#define SDR_LD_NT 1
+#endif
+#ifndef SDR_ST_NT
+#define SDR_ST_NT 1
+#endif
+
 namespace sdr_amd {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <class T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if SDR_LD_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void stream_store(T v, T* p) {
+#if SDR_ST_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 namespace {
 
@@ -308,9 +333,9 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
         for (int n2 = 0; n2 < 16; ++n2) {
             if (REAL) {
                 const float* q = p0 + 256 * n2;
-                dst[n2] = f2{__builtin_nontemporal_load(q + tid), __builtin_nontemporal_load(q + D + tid)};
+                dst[n2] = f2{stream_load(q + tid), stream_load(q + D + tid)};
             } else {
-                dst[n2] = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
+                dst[n2] = stream_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
             }
         }
     };
@@ -456,10 +481,10 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
             const f2 y = w[P16(n2)];
             if (REAL) {
                 float* q = q0 + 256 * n2;
-                __builtin_nontemporal_store(y.x, q + tid);
-                __builtin_nontemporal_store(y.y, q + D + tid);
+                stream_store(y.x, q + tid);
+                stream_store(y.y, q + D + tid);
             } else {
-                __builtin_nontemporal_store(y, reinterpret_cast<f2*>(q0 + 512 * n2) + tid);
+                stream_store(y, reinterpret_cast<f2*>(q0 + 512 * n2) + tid);
             }
         }
         cur = advance(cur);
