@@ -44,12 +44,27 @@ __global__ __launch_bounds__(256, 3) void copy_tiles(const f2* __restrict__ in, 
         for (int k = 0; k < 16; ++k)
             for (int s = 0; s < SPIN; ++s) v[k] = v[k] * 1.0001f + 0.0001f;
         for (int x = 0; x < XCH; ++x) {
-            __syncthreads();
+            // XCH < 10: block-wide exchanges (two block barriers each).  XCH = 12: the real
+            // kernel's pattern -- exchanges 0 and 5 block-wide with ONE barrier each (columns
+            // are private to a wave on one side), exchanges 1-4 inside 16-lane groups.
+            const bool block_wide = XCH < 10 || x == 0 || x == 5;
+            if (XCH >= 10 && x >= 6) break;
+            if (XCH < 10) __syncthreads();
+            if (block_wide) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) xch[k * 272 + tid] = v[k];
-            __syncthreads();
+                for (int k = 0; k < 16; ++k) xch[k * 272 + tid] = v[k];
+                __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = xch[(tid >> 4) * 272 + 16 * k + (tid & 15)] * 1.0001f;
+                for (int k = 0; k < 16; ++k) v[k] = xch[(tid >> 4) * 272 + 16 * k + (tid & 15)] * 1.0001f;
+            } else {
+                f2* row = xch + (tid >> 4) * 272;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) row[k * 17 + (tid & 15)] = v[k];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = row[(tid & 15) * 17 + k] * 1.0001f;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 15; ++k) __builtin_nontemporal_store(v[k + 1], &out[t * 3840 + 256 * k + tid]);
@@ -78,13 +93,12 @@ int main() {
         float t;
 #define RUN(SPIN, XCH, PAD, WHAT) t = timeit([&] { hipLaunchKernelGGL((copy_tiles<false, SPIN, XCH, PAD>), dim3(grid), dim3(256), 0, 0, in, out, tiles, ctr); }); \
         printf("%s: %4d packed ops/lane/tile, %d LDS exchanges: %.3f ms %.0f GB/s\n", WHAT, 16 * SPIN, XCH, t, gb / t * 1e3);
-        RUN(40, 6, 42, "2 workgroups/CU (77 KB LDS each)")
-        RUN(40, 6, 17, "3 workgroups/CU (52 KB LDS each)")
-        RUN(40, 6, 4, "4 workgroups/CU (39 KB LDS each)")
-        RUN(40, 6, 0, "4 workgroups/CU (35 KB LDS each)")
-        RUN(0, 0, 42, "2 workgroups/CU (77 KB LDS each)")
-        RUN(0, 0, 17, "3 workgroups/CU (52 KB LDS each)")
-        RUN(0, 0, 4, "4 workgroups/CU (39 KB LDS each)")
+        RUN(40, 12, 17, "3 workgroups/CU, real pattern (2 block-wide + 4 group exchanges)")
+        RUN(40, 12, 4, "4 workgroups/CU, real pattern")
+        RUN(0, 12, 17, "3 workgroups/CU, real pattern, no ALU work")
+        RUN(40, 0, 17, "3 workgroups/CU, ALU work only")
+        RUN(40, 6, 17, "3 workgroups/CU, 6 block-wide exchanges")
+        RUN(0, 0, 17, "3 workgroups/CU, copy only")
     }
     return 0;
 }
