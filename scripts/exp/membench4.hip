@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256, 3) void copy_tiles(const f2* __restrict__ in, 
             // XCH < 10: block-wide exchanges (two block barriers each).  XCH = 12: the real
             // kernel's pattern -- exchanges 0 and 5 block-wide with ONE barrier each (columns
             // are private to a wave on one side), exchanges 1-4 inside 16-lane groups.
-            const bool block_wide = XCH < 10 || x == 0 || x == 5;
-            if (XCH >= 10 && x >= 6) break;
+            // XCH = 11: 2 block-wide + 2 group exchanges (the kernel's actual count)
+            const int last = XCH == 11 ? 3 : 5;
+            const bool block_wide = XCH < 10 || x == 0 || x == last;
+            if (XCH >= 10 && x > last) break;
             if (XCH < 10) __syncthreads();
             if (block_wide) {
 #pragma unroll
@@ -93,6 +95,8 @@ int main() {
         float t;
 #define RUN(SPIN, XCH, PAD, WHAT) t = timeit([&] { hipLaunchKernelGGL((copy_tiles<false, SPIN, XCH, PAD>), dim3(grid), dim3(256), 0, 0, in, out, tiles, ctr); }); \
         printf("%s: %4d packed ops/lane/tile, %d LDS exchanges: %.3f ms %.0f GB/s\n", WHAT, 16 * SPIN, XCH, t, gb / t * 1e3);
+        RUN(40, 11, 17, "3 workgroups/CU, 2 block-wide + 2 group exchanges (the kernel's count)")
+        RUN(43, 11, 17, "3 workgroups/CU, same with 690 ops")
         RUN(40, 12, 17, "3 workgroups/CU, real pattern (2 block-wide + 4 group exchanges)")
         RUN(40, 12, 4, "4 workgroups/CU, real pattern")
         RUN(0, 12, 17, "3 workgroups/CU, real pattern, no ALU work")
