@@ -9,7 +9,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // PADKB: extra LDS per workgroup, to set how many workgroups fit a CU (160 KB)
-template <bool DYN, int SPIN, int XCH = 0, int PADKB = 0>
+template <bool DYN, int SPIN, int XCH = 0, int PADKB = 0, int SPLIT = 0>
 __global__ __launch_bounds__(256, 3) void copy_tiles(const f2* __restrict__ in, f2* __restrict__ out, long long tiles,
                                                      unsigned* counter) {
     __shared__ long long next_tile;
@@ -36,8 +36,10 @@ __global__ __launch_bounds__(256, 3) void copy_tiles(const f2* __restrict__ in, 
         long long tn = DYN ? grab() : t + gridDim.x;
         const bool more = tn < tiles;
         const long long tl = more ? tn : t;
+        if (!SPLIT) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) nx[k] = __builtin_nontemporal_load(&in[tl * 3840 + 256 * k + tid]);
+            for (int k = 0; k < 16; ++k) nx[k] = __builtin_nontemporal_load(&in[tl * 3840 + 256 * k + tid]);
+        }
         // stand-in for the transform: SPIN dependent packed ops per point, XCH exchanges
         // of the whole tile through LDS with a block barrier each
 #pragma unroll
@@ -49,6 +51,10 @@ __global__ __launch_bounds__(256, 3) void copy_tiles(const f2* __restrict__ in, 
             // are private to a wave on one side), exchanges 1-4 inside 16-lane groups.
             // XCH = 11: 2 block-wide + 2 group exchanges (the kernel's actual count)
             const int last = XCH == 11 ? 3 : 5;
+            if (SPLIT && x < 4) { // a quarter of the next tile's loads before each of the first four exchanges
+#pragma unroll
+                for (int k = 4 * x; k < 4 * x + 4; ++k) nx[k] = __builtin_nontemporal_load(&in[tl * 3840 + 256 * k + tid]);
+            }
             const bool block_wide = XCH < 10 || x == 0 || x == last;
             if (XCH >= 10 && x > last) break;
             if (XCH < 10) __syncthreads();
@@ -96,6 +102,8 @@ int main() {
 #define RUN(SPIN, XCH, PAD, WHAT) t = timeit([&] { hipLaunchKernelGGL((copy_tiles<false, SPIN, XCH, PAD>), dim3(grid), dim3(256), 0, 0, in, out, tiles, ctr); }); \
         printf("%s: %4d packed ops/lane/tile, %d LDS exchanges: %.3f ms %.0f GB/s\n", WHAT, 16 * SPIN, XCH, t, gb / t * 1e3);
         RUN(40, 11, 17, "3 workgroups/CU, 2 block-wide + 2 group exchanges (the kernel's count)")
+        t = timeit([&] { hipLaunchKernelGGL((copy_tiles<false, 40, 11, 17, 1>), dim3(grid), dim3(256), 0, 0, in, out, tiles, ctr); });
+        printf("same, next tile's loads spread over the four exchanges: %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
         RUN(43, 11, 17, "3 workgroups/CU, same with 690 ops")
         RUN(40, 12, 17, "3 workgroups/CU, real pattern (2 block-wide + 4 group exchanges)")
         RUN(40, 12, 4, "4 workgroups/CU, real pattern")

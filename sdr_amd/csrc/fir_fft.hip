@@ -42,6 +42,9 @@
 #ifndef SDR_ST_NT
 #define SDR_ST_NT 1
 #endif
+#ifndef SDR_SPREAD
+#define SDR_SPREAD 1
+#endif
 
 namespace sdr_amd {
 
@@ -115,6 +118,7 @@ __device__ __forceinline__ void radix4(f2& x0, f2& x1, f2& x2, f2& x3) {
 
 // In-place 16-point DFT (INV: inverse, unscaled).  Input v[n] in natural order;
 // output X[k] is left at v[P16(k)], P16(k) = 4*(k&3) + (k>>2).
+template <int V> struct IC { static constexpr int value = V; };
 __host__ __device__ constexpr int P16(int k) { return 4 * (k & 3) + (k >> 2); }
 
 template <bool INV>
@@ -239,8 +243,10 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
 
 // Inverse transform: w[k2] = Y[(tid>>4) + 16 (tid&15) + 256 k2] in (natural k2 order),
 // y[256 n2 + tid] left at w[P16(n2)].
-template <class Consts>
-__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const Consts& c) {
+// `before_barrier` runs after the last group-local write, ahead of the block barrier (a
+// slot for a share of the next tile's loads).
+template <class Consts, class Hook>
+__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const Consts& c, Hook&& before_barrier) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW;
     // ---- C': over k2 -> n0 --------------------------------------------------------
@@ -258,6 +264,7 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) row1[16 * n1 + l16] = w[P16(n1)];
+    before_barrier();
     __syncthreads();
     // ---- A': lane r: conj twiddle, over k0 -> n2 ----------------------------------
 #pragma unroll
@@ -298,6 +305,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
     static_assert(!GEN || REAL, "the generator source produces real samples");
     const int tid = threadIdx.x;
+    constexpr bool SPREAD = !LONG && SDR_SPREAD; // single-spectrum variants: spread the prefetch (see the main loop)
     constexpr int W = REAL ? 1 : 2;
     constexpr long long L = FFT_N - 256 * HB;
     constexpr long long per_tile = REAL ? 2 * L : L;
@@ -327,6 +335,18 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
     };
     auto in_ptr = [&](Pos p) -> const float* {            // wave-uniform pointer to x[s0]
         return a.in + (p.ch * a.in_stride + first_out(p) - 256 * HB) * W;
+    };
+    // rows [LO, HI) of a tile's 16 rows of 256 points
+    auto load_rows = [&](const float* p0, f2 (&dst)[16], auto lo, auto hi) {
+#pragma unroll
+        for (int n2 = decltype(lo)::value; n2 < decltype(hi)::value; ++n2) {
+            if (REAL) {
+                const float* q = p0 + 256 * n2;
+                dst[n2] = f2{stream_load(q + tid), stream_load(q + D + tid)};
+            } else {
+                dst[n2] = stream_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
+            }
+        }
     };
     auto load = [&](const float* p0, f2 (&dst)[16]) {
 #pragma unroll
@@ -452,7 +472,16 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[P16(k)] = v[k];
         } else {
-            forward_tile(v, lds, tid, c, [&] { if constexpr (!GEN) load(pn, nx); }, after_forward);
+            // the next tile's 16 loads go out in three shares spread over this tile's phases
+            // (5 rows here, 5 after the forward transform, 6 inside the inverse): the memory
+            // system sees a steadier request stream than one burst per tile (+2 %)
+            forward_tile(v, lds, tid, c, [&] {
+                if constexpr (!GEN) {
+                    if constexpr (SPREAD) load_rows(pn, nx, IC<0>{}, IC<5>{});
+                    else load(pn, nx);
+                }
+            }, after_forward);
+            if constexpr (!GEN && SPREAD) load_rows(pn, nx, IC<5>{}, IC<10>{});
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
             if (CACHE) {
@@ -473,7 +502,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
                     }
                 }
             }
-            inverse_tile(w, lds, tid, c);
+            inverse_tile(w, lds, tid, c, [&] { if constexpr (!GEN && SPREAD) load_rows(pn, nx, IC<10>{}, IC<16>{}); });
         }
         float* q0 = a.out + (cur.ch * a.out_stride + first_out(cur) - 256 * HB) * W; // &y[-halo] of the tile
 #pragma unroll
@@ -545,7 +574,7 @@ __device__ __forceinline__ void edge_tiles(const FftArgs& a, f2* lds, const Cons
                 w[k] = p == 0 ? t : w[k] + t;
             }
         }
-        inverse_tile(w, lds, tid, c);
+        inverse_tile(w, lds, tid, c, [] {});
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             const int m = 256 * n2 + tid - halo;
