@@ -3,7 +3,10 @@
 unix pipes -- the drop-in blocks (blocks/bin, GPU) beside the reference's own blocks
 (oracle/_ref, CPU, built from /root/reference in the build container) on the same box.
 
-    python scripts/bench_pipe.py [--log2n 24] [--procs P]
+    python tests/pipe_end_to_end.py [--log2n 24] [--procs P]
+
+(kept under tests/ because it runs the reference binaries of oracle/_ref as the checker and
+comparator; pytest does not collect it -- tests/test_blocks_gpu.py holds the small version.)
 
 Prints one JSON object: wall time and Msamples/s of each pipeline (PCIe- and pipe-
 inclusive: this is NOT bench.py's `value`), the reference `hilbert` alone from a
@@ -22,7 +25,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 BIN = os.path.join(ROOT, "blocks", "bin")
 REF = os.path.join(ROOT, "oracle", "_ref")
 HDR = struct.Struct("<HHIQ")
