@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=27)
+    ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--chunk-log2", type=int, default=29, help="c5: samples per call")
     ap.add_argument("--unfused", action="store_true", help="c5: generator kernel + chain kernel through an HBM buffer")
     args = ap.parse_args()
