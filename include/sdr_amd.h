@@ -166,7 +166,8 @@ int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample);
 /* The phase recurrence of the generator loop (blocks/gen.cpp:185 `phi = fract(phi +
  * phi_incr)`) run `blocks` times without producing samples: positions the generator
  * at packet `blocks` further on, bit-for-bit where the reference would be (a rank that
- * owns a later chunk of the stream starts here). */
+ * owns a later chunk of the stream starts here).  Not for complex square / triangle /
+ * sawtooth, whose quadrature filter history cannot be skipped. */
 int sdr_gen_advance(sdr_gen_t* g, size_t blocks);
 /* Replaces the body of the generator loop (blocks/gen.cpp:183-195, 224-229):
  * the next `blocks` packets' worth of samples, bit-for-bit the reference's fp32

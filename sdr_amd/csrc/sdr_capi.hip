@@ -509,6 +509,8 @@ extern "C" int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample) {
 extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
     clear_error();
     if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_advance: NULL handle");
+    if (g->quadrature() && blocks)
+        return fail(SDR_ERR_INVALID, "sdr_gen_advance: a quadrature generator carries a filter history that cannot be skipped");
     float phi = g->phi;
     const float incr = g->phi_incr;
     for (size_t b = 0; b < blocks; ++b) phi = fractf_host(phi + incr);
