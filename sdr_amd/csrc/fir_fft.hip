@@ -281,7 +281,7 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 }
 
 // ---- interior tiles: straight-line, software-pipelined -----------------------------
-// Tiles whose inputs and outputs all lie inside [0, n).  halo = 256*HB is a
+// Tiles whose inputs and outputs all lie inside [0, n).  halo = 64*HQ is a
 // compile-time constant so that loads and stores are unconditional and the compiler's
 // vmcnt bookkeeping is exact: the next tile's 16 loads are issued right after the
 // current points have left the registers and are only waited for at the top of the
@@ -298,16 +298,18 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // generator's recipe (gen_device.h) instead of being loaded -- the fused
 // gen -> hilbert -> FIR chain writes 4 bytes per sample and reads none.
 // Workgroup `bid` of `nblk` interior workgroups.
-template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE, bool GEN>
+template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
 __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const LaneConstsT<TBL, false>& c, const int bid,
                                                const int nblk) {
-    static_assert(!LONG || HB == 8, "partitioned mode uses hop 2048");
+    static_assert(!LONG || HQ == 32, "partitioned mode uses hop 2048");
+    static_assert(HQ >= 1 && HQ <= 32 && (HQ & (HQ - 1)) == 0, "halo = 64 * {1,2,4,8,16,32}");
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
     static_assert(!GEN || REAL, "the generator source produces real samples");
     const int tid = threadIdx.x;
     constexpr bool SPREAD = !LONG && SDR_SPREAD; // single-spectrum variants: spread the prefetch (see the main loop)
     constexpr int W = REAL ? 1 : 2;
-    constexpr long long L = FFT_N - 256 * HB;
+    constexpr int HALO = 64 * HQ;
+    constexpr long long L = FFT_N - HALO;
     constexpr long long per_tile = REAL ? 2 * L : L;
     const long long inner = a.t_hi - a.t_lo;             // interior tiles per channel
     const long long total = inner * a.channels;
@@ -334,7 +336,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
         return p.tt * per_tile;
     };
     auto in_ptr = [&](Pos p) -> const float* {            // wave-uniform pointer to x[s0]
-        return a.in + (p.ch * a.in_stride + first_out(p) - 256 * HB) * W;
+        return a.in + (p.ch * a.in_stride + first_out(p) - HALO) * W;
     };
     // rows [LO, HI) of a tile's 16 rows of 256 points
     auto load_rows = [&](const float* p0, f2 (&dst)[16], auto lo, auto hi) {
@@ -419,7 +421,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
     // partitioned mode): loaded, or synthesised
     auto fetch = [&](Pos p, long long back, f2 (&dst)[16]) {
         if constexpr (GEN) {
-            synth(first_out(p) - 256 * HB - back, dst);
+            synth(first_out(p) - HALO - back, dst);
         } else {
             load(in_ptr(p) - back * W, dst);
         }
@@ -504,9 +506,12 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
             }
             inverse_tile(w, lds, tid, c, [&] { if constexpr (!GEN && SPREAD) load_rows(pn, nx, IC<10>{}, IC<16>{}); });
         }
-        float* q0 = a.out + (cur.ch * a.out_stride + first_out(cur) - 256 * HB) * W; // &y[-halo] of the tile
+        float* q0 = a.out + (cur.ch * a.out_stride + first_out(cur) - HALO) * W; // &y[-halo] of the tile
 #pragma unroll
-        for (int n2 = HB; n2 < 16; ++n2) {
+        for (int n2 = HALO / 256; n2 < 16; ++n2) {
+            // a halo that ends inside a row (64 or 128 samples): the row's first waves hold
+            // halo positions and store nothing -- a wave-uniform predicate
+            if (n2 == HALO / 256 && HALO % 256 != 0 && tid < HALO % 256) continue;
             const f2 y = w[P16(n2)];
             if (REAL) {
                 float* q = q0 + 256 * n2;
@@ -614,7 +619,7 @@ __device__ __forceinline__ void carry_history(const FftArgs& a, const int w, con
 // next a.grid_edge take the edge tiles, the rest are the persistent interior
 // workgroups: the few slow, bounds-checked tiles start first and overlap the bulk
 // instead of trailing it as separate launches.
-template <bool REAL, int HB, bool LONG, bool TBL, bool CACHE, bool GEN>
+template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
 __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     int bid = blockIdx.x;
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
         bid -= a.grid_edge;
     }
     c.init(threadIdx.x, a.hperm, !LONG, TBL ? lds + 16 * ROW : nullptr);
-    interior_tiles<REAL, HB, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
+    interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
                                                     LONG ? (int)gridDim.x : (int)gridDim.x - a.grid_carry - a.grid_edge);
 }
 
@@ -661,8 +666,8 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
     if (a.parts > 1) {
         const dim3 g((unsigned)grid_int);
         if (grid_int > 0) {
-            if (a.parts == 2 && !(a.ablate & 4)) hipLaunchKernelGGL((fir_fft4096<REAL, 8, true, true, true, GEN>), g, b, 0, stream, a);
-            else hipLaunchKernelGGL((fir_fft4096<REAL, 8, true, false, false, GEN>), g, b, 0, stream, a);
+            if (a.parts == 2 && !(a.ablate & 4)) hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, true, true, GEN>), g, b, 0, stream, a);
+            else hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, false, false, GEN>), g, b, 0, stream, a);
         }
         if (n_short > 0) hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN>), dim3((unsigned)n_short), b, 0, stream, a);
         return hipGetLastError();
@@ -670,22 +675,25 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
     const dim3 g((unsigned)(grid_int + n_short));
     // W_256 twiddles from the LDS table: 161 VGPRs, three workgroups per CU (+3 % over
     // the all-register build at two per CU, profiles/r01_fft_variants.txt)
-    switch (a.halo / 256) {
+    switch (a.halo / 64) {
         case 1: hipLaunchKernelGGL((fir_fft4096<REAL, 1, false, true, false, GEN>), g, b, 0, stream, a); break;
         case 2: hipLaunchKernelGGL((fir_fft4096<REAL, 2, false, true, false, GEN>), g, b, 0, stream, a); break;
         case 4: hipLaunchKernelGGL((fir_fft4096<REAL, 4, false, true, false, GEN>), g, b, 0, stream, a); break;
         case 8: hipLaunchKernelGGL((fir_fft4096<REAL, 8, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 16: hipLaunchKernelGGL((fir_fft4096<REAL, 16, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 32: hipLaunchKernelGGL((fir_fft4096<REAL, 32, false, true, false, GEN>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-// Tiling for a tap count: halo = 256 * {1,2,4,8} old samples per tile for up to 2049
-// taps (one spectrum); beyond that hop 2048 with ceil(ntaps/2048) partitions.
+// Tiling for a tap count: halo = 64 * {1,2,4,8,16,32} old samples per tile for up to 2049
+// taps (one spectrum; 127 taps -> 128, i.e. 3968 new samples per 4096-point tile); beyond
+// that hop 2048 with ceil(ntaps/2048) partitions.
 void fir_fft_plan(size_t ntaps, int* halo, int* parts) {
     *parts = 1;
-    for (int hb : {1, 2, 4, 8})
-        if (ntaps <= (size_t)256 * hb + 1) { *halo = 256 * hb; return; }
+    for (int hq : {1, 2, 4, 8, 16, 32})
+        if (ntaps <= (size_t)64 * hq + 1) { *halo = 64 * hq; return; }
     *halo = 2048;
     *parts = (int)((ntaps + 2047) / 2048);
 }

@@ -42,7 +42,7 @@ struct FftArgs {
     long long in_stride;
     long long out_stride;
     long long channels;
-    int halo;             // old samples per tile: >= ntaps-1; 256 * {1,2,4,8}
+    int halo;             // old samples per tile: >= ntaps-1; 64 * {1,2,4,8,16,32}
     int hist_len;         // >= halo
     int ablate;           // diagnostics (SDR_AMD_FFT_ABLATE): 1 = skip the arithmetic (memory pattern only)
     int parts;            // filter partitions of 2048 taps (1 = plain overlap-save)
