@@ -185,7 +185,7 @@ void sdr_gen_destroy(sdr_gen_t* g);
  * written to memory (the few packets that overlap the start-of-stream warm-up are
  * materialised once, in a buffer the first call allocates).  Same results as
  * sdr_gen_generate_device followed by sdr_chain_process_device.  Real generator,
- * real one-channel chain whose combined filter has >= 48 taps (>= 100 if every other tap is zero), packets of 256..2^23
+ * real one-channel chain whose combined filter has >= 41 taps (>= 96 if every other tap is zero), packets of 256..2^23
  * samples; *n_out outputs are written from d_out (DEVICE memory), asynchronously on
  * hip_stream. */
 int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t blocks, void* d_out, size_t* n_out,

@@ -139,8 +139,10 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     int fft_halo = 0, fft_parts = 1;
     fir_fft_plan(ntaps, &fft_halo, &fft_parts);
     // Measured crossover (profiles/r01_direct_vs_fft_crossover.txt): the direct form holds
-    // its memory-bound floor (5.7 TB/s) up to ~47 dense or ~95 Hilbert-structured taps.
-    bool use_fft = ntaps >= (stride == 2 ? 100u : 48u) && fft_parts <= 64;
+    // its memory-bound floor (5.7 TB/s) up to 32 dense taps (40 on real samples) or ~95
+    // Hilbert-structured taps; from there the fast convolution is quicker.
+    const size_t fft_from = stride == 2 ? 96u : sample_kind == SDR_COMPLEX ? 33u : 41u;
+    bool use_fft = ntaps >= fft_from && fft_parts <= 64;
     if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_parts <= 64;
 
     int R = env_int("SDR_AMD_R", 8);

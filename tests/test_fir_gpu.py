@@ -120,7 +120,7 @@ def test_single_call_vs_oracle(kind, ntaps, cplx):
     n = 20011  # ragged: not a multiple of any tile size
     x = rand(rng, n, cplx)
     st = sdr_amd.FirState(taps, cplx)
-    if kind == "hilbert" and 8 <= ntaps < 100:
+    if kind == "hilbert" and 8 <= ntaps < 96:
         assert st.tap_stride == 2, "short Hilbert taps must select the zero-skipping direct kernel"
     y = sdr_amd.fir(st, x)
     ref = O.fir(taps, x)
