@@ -30,6 +30,26 @@ FirPipeline::~FirPipeline() {
     sdr_fir_destroy(fir_[1]);
 }
 
+// A packet larger than the batch size gets a batch of its own, grown to fit (the wire
+// format allows payloads up to 4 GiB; the reference reads any packet whole).
+bool FirPipeline::grow(Batch& b, size_t bytes) {
+    if (bytes <= b.cap_bytes) return true;
+    bytes = (bytes + ((1u << 20) - 1)) & ~size_t((1u << 20) - 1);
+    float* in = static_cast<float*>(sdr_host_alloc(bytes));
+    float* out = static_cast<float*>(sdr_host_alloc(bytes));
+    if (!in || !out) {
+        sdr_host_free(in);
+        sdr_host_free(out);
+        return false;
+    }
+    sdr_host_free(b.in);
+    sdr_host_free(b.out);
+    b.in = in;
+    b.out = out;
+    b.cap_bytes = bytes;
+    return true;
+}
+
 bool FirPipeline::is_filtered(const PacketHeader& h) const {
     if (h.content != kSignal && h.content != kComplexSignal) return false;
     if (cfg_.select) return cfg_.select(h, cfg_.select_ctx);
@@ -192,9 +212,7 @@ int FirPipeline::run(int in_fd, int out_fd) {
     }
     pool_.resize(kPoolSize);
     for (auto& b : pool_) {
-        b.in = static_cast<float*>(sdr_host_alloc(cfg_.batch_bytes));
-        b.out = static_cast<float*>(sdr_host_alloc(cfg_.batch_bytes));
-        if (!b.in || !b.out) return report("pinned host allocation failed");
+        if (!grow(b, cfg_.batch_bytes)) return report("pinned host allocation failed");
         free_.push_back(&b);
     }
     writer_ = std::thread([this, out_fd] { writer_loop(out_fd); });
@@ -253,13 +271,19 @@ int FirPipeline::run(int in_fd, int out_fd) {
             const size_t elt = cplx ? 8 : 4;
             // Packet::count<T>() is 0 unless size is a whole number of samples
             const size_t want = (h.size % elt) ? 0 : h.size / elt;
-            if (want * elt > cfg_.batch_bytes) {
-                std::cerr << "error: packet larger than the batch buffer" << std::endl;
-                rc = -1;
-                break;
-            }
-            if (cur->samples && (cur->complex_samples != cplx || (cur->samples + want) * elt > cfg_.batch_bytes))
+            if (cur->samples && (cur->complex_samples != cplx || (cur->samples + want) * elt > cur->cap_bytes))
                 if ((rc = flush(false))) break;
+            if (want * elt > cur->cap_bytes) {
+                // cur holds no samples here (just flushed, or fresh) -- but it may hold
+                // forwarded packets whose order must be kept: hand those on first
+                if (!cur->items.empty())
+                    if ((rc = flush(false))) break;
+                if (!grow(*cur, want * elt)) {
+                    std::cerr << "error: cannot allocate a " << want * elt << "-byte pinned buffer for one packet" << std::endl;
+                    rc = -1;
+                    break;
+                }
+            }
             if (cur->samples == 0) cur->complex_samples = cplx;
             uint8_t* dst = reinterpret_cast<uint8_t*>(cur->in) + cur->samples * elt;
             const size_t got = rd.read_payload(dst, want * elt) / elt;

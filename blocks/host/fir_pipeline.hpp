@@ -62,9 +62,11 @@ private:
         std::vector<uint8_t> raw;
         std::vector<Item> items;
         size_t samples = 0;
+        size_t cap_bytes = 0; // size of `in` and of `out`
         bool complex_samples = false;
         int slot = -1;
     };
+    bool grow(Batch& b, size_t bytes); // pinned buffers of at least `bytes` (contents dropped)
 
     bool is_filtered(const PacketHeader& h) const;
     int launch(Batch& b);           // queue on the GPU

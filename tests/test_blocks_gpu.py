@@ -89,6 +89,28 @@ def test_hilbert_block_mixed_content_shares_history():
     assert rel_err(samples(got), samples(want)) <= TOL
 
 
+def test_hilbert_block_packet_larger_than_a_batch():
+    """The wire format allows payloads up to 4 GiB and the reference reads any packet whole:
+    a packet bigger than the batch size gets a batch of its own, between ordinary packets and
+    a forwarded one, with order and arithmetic unchanged."""
+    rng = np.random.default_rng(5)
+    sizes = [1000, 100000, 7, 30000]
+    xs = [rng.uniform(-1, 1, n).astype(np.float32) for n in sizes]
+    stream = b"".join([O.pack_packet(0, O.SIGNAL, xs[0].tobytes(), 1000),
+                       O.pack_packet(9, 1, b"between", 5),
+                       O.pack_packet(0, O.SIGNAL, xs[1].tobytes(), 100000),
+                       O.pack_packet(0, O.SIGNAL, xs[2].tobytes(), 7),
+                       O.pack_packet(0, O.SIGNAL, xs[3].tobytes(), 30000)])
+    out = run_block("hilbert", [], stream, {"SDR_AMD_BATCH_BYTES": "65536"})
+    got = O.parse_packets(out)
+    ref = O.parse_packets(O.hilbert_block(stream))
+    assert [p[:4] for p in got] == [p[:4] for p in ref]
+    assert got[1][4] == b"between"
+    a = samples([p for p in got if p[1] == O.SIGNAL])
+    b = samples([p for p in ref if p[1] == O.SIGNAL])
+    assert rel_err(a, b) <= TOL
+
+
 def test_gen_block_matches_reference_packets(golden_dir):
     g = np.load(os.path.join(golden_dir, "gen.npz"))
     cases = {
