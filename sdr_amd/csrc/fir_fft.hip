@@ -147,55 +147,52 @@ __device__ __forceinline__ void dft16(f2 (&v)[16]) {
     for (int c = 0; c < 4; ++c) radix4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
-__device__ __forceinline__ f2 unit_root(int m, int M) { // exp(-2 pi i m / M)
-    float s, c;
-    sincospif(-2.0f * (float)m / (float)M, &s, &c);
-    return f2{c, s};
-}
-
 } // namespace
 
 // Per-lane constants, computed once per (persistent) workgroup and kept in VGPRs:
 //   TA[k] = W_4096^(tid k), TB[k] = W_256^((tid&15) k), H[k2] = spectrum/N of bin
 //   (tid>>4) + 16 (tid&15) + 256 k2.
 // TBL: the W_256 twiddles are read from a 256-entry LDS table instead of 30 VGPRs.
-// TAL: the W_4096 twiddles too, from a lane-private LDS column ([k][tid], 30 KB per
-// workgroup): for the variants that run two workgroups per CU and need the registers.
-template <bool TBL, bool TAL = false>
+template <bool TBL>
 struct LaneConstsT {
-    f2 TA[TAL ? 1 : 16], TB[TBL ? 1 : 16], H[16];
+    f2 TA[16], TB[TBL ? 1 : 16], H[16];
     const f2* tb_lds;
-    const f2* ta_lds;
     __device__ __forceinline__ f2 tb(int k) const {
         if constexpr (TBL) return tb_lds[16 * k];
         else return TB[k];
     }
-    __device__ __forceinline__ f2 ta(int k) const {
-        if constexpr (TAL) return ta_lds[256 * k];
-        else return TA[k];
-    }
-    // table: 256 entries (TBL) followed by 16 x 256 entries (TAL)
-    __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum, f2* table = nullptr) {
-        tb_lds = ta_lds = nullptr;
-        if constexpr (TAL) {
-            f2* col = table + 256 + tid;
+    __device__ __forceinline__ f2 ta(int k) const { return TA[k]; }
+    // wtab = exp(-2 pi i m / 4096), m = 0..4095, computed once per filter on the host
+    // (double, rounded to fp32).  A workgroup copies it into the exchange buffer `stage`
+    // (>= 4096 entries) with 16 coalesced loads per lane and picks its twiddles out of LDS:
+    // 32 KB of L2 traffic and no sincos evaluation (30 of them per lane cost three tiles'
+    // worth of arithmetic -- most of a short call).  `table`: 256 entries for TBL.
+    __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum, const f2* wtab, f2* stage,
+                                         f2* table = nullptr) {
+        tb_lds = nullptr;
 #pragma unroll
-            for (int k = 1; k < 16; ++k) col[256 * k] = unit_root((tid * k) & 4095, 4096);
-            ta_lds = col;
-        } else {
+        for (int k = 0; k < 16; ++k) stage[256 * k + tid] = wtab[256 * k + tid];
+        __syncthreads();
 #pragma unroll
-            for (int k = 1; k < 16; ++k) TA[k] = unit_root((tid * k) & 4095, 4096);
-        }
+        for (int k = 1; k < 16; ++k) TA[k] = stage[(tid * k) & 4095];
         if constexpr (TBL) {
             // table[16 k + n] = W_256^(n k); a lane reads column n = tid & 15 (broadcast within 16-lane groups)
-            table[tid] = unit_root(((tid & 15) * (tid >> 4)) & 255, 256);
+            table[tid] = stage[16 * (((tid & 15) * (tid >> 4)) & 255)];
             tb_lds = table + (tid & 15);
-            __syncthreads();
         } else {
             (void)table;
 #pragma unroll
-            for (int k = 1; k < 16; ++k) TB[k] = unit_root(((tid & 15) * k) & 255, 256);
+            for (int k = 1; k < 16; ++k) TB[k] = stage[16 * (((tid & 15) * k) & 255)];
         }
+        // Pin the LDS reads above ahead of the barrier: left alone, the compiler sinks them
+        // below it (a plain load may move past an acquire), to where other waves are already
+        // writing their first tile into the exchange buffer.
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            asm volatile("" : "+v"(TA[k].x), "+v"(TA[k].y));
+            if constexpr (!TBL) asm volatile("" : "+v"(TB[k].x), "+v"(TB[k].y));
+        }
+        __syncthreads(); // the exchange buffer is free again; the table is published
         if (with_spectrum) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) H[k] = reinterpret_cast<const f2*>(hperm)[k * 256 + tid];
@@ -299,7 +296,7 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // gen -> hilbert -> FIR chain writes 4 bytes per sample and reads none.
 // Workgroup `bid` of `nblk` interior workgroups.
 template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
-__device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const LaneConstsT<TBL, false>& c, const int bid,
+__device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneConstsT<TBL>& c, const int bid,
                                                const int nblk) {
     static_assert(!LONG || HQ == 32, "partitioned mode uses hop 2048");
     static_assert(HQ >= 1 && HQ <= 32 && (HQ & (HQ - 1)) == 0, "halo = 64 * {1,2,4,8,16,32}");
@@ -445,6 +442,9 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, const 
     }
     f2 nx[GEN ? 1 : 16]; // the next tile's points, loaded one tile ahead (nothing to prefetch with GEN)
     if constexpr (!GEN) load(in_ptr(cur), nx);
+    // the lane constants are set up with the first tile's loads already in flight (every
+    // lane of the workgroup gets here or none does: the returns above are uniform)
+    c.init(tid, a.hperm, !LONG, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
 
     auto body = [&]() {
         f2 v[16];
@@ -623,7 +623,7 @@ template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
 __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     int bid = blockIdx.x;
-    LaneConstsT<TBL, false> c;
+    LaneConstsT<TBL> c;
     // (the partitioned variants keep their short work in a launch of its own,
     // fir_fft4096_short: sharing a kernel with it costs their main loop 20 %)
     if constexpr (!LONG) {
@@ -633,13 +633,12 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
         }
         bid -= a.grid_carry;
         if (bid < a.grid_edge) {
-            c.init(threadIdx.x, a.hperm, false, TBL ? lds + 16 * ROW : nullptr);
+            c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
             edge_tiles<REAL, GEN>(a, lds, c, bid, a.grid_edge);
             return;
         }
         bid -= a.grid_edge;
     }
-    c.init(threadIdx.x, a.hperm, !LONG, TBL ? lds + 16 * ROW : nullptr);
     interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
                                                     LONG ? (int)gridDim.x : (int)gridDim.x - a.grid_carry - a.grid_edge);
 }
@@ -655,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
     }
     bid -= a.grid_carry;
     LaneConstsT<true> c;
-    c.init(threadIdx.x, a.hperm, false, lds + 16 * ROW);
+    c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, lds + 16 * ROW);
     edge_tiles<REAL, GEN>(a, lds, c, bid, a.grid_edge);
 }
 

@@ -77,6 +77,7 @@ struct sdr_fir {
     int fft_grid = 0;
     int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
     float* d_hperm = nullptr;
+    const float* d_wtab = nullptr; // twiddle table, stored behind the spectra in d_hperm
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     hipStream_t stream = nullptr; // used by the host-buffer entry points
@@ -206,7 +207,11 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
         }
         // partition p holds taps [p*2048, p*2048+2048) (all taps when parts == 1)
         const size_t plen = fft_parts > 1 ? 2048 : ntaps;
-        std::vector<float> hp((size_t)2 * N * fft_parts);
+        std::vector<float> hp((size_t)2 * N * (fft_parts + 1)); // spectra, then the twiddle table
+        for (int m = 0; m < N; ++m) {
+            hp[(size_t)2 * N * fft_parts + 2 * m] = (float)cs[m];
+            hp[(size_t)2 * N * fft_parts + 2 * m + 1] = (float)-sn[m];
+        }
         for (int p = 0; p < fft_parts; ++p) {
             const size_t j0 = (size_t)p * plen, j1 = std::min(ntaps, j0 + plen);
             for (int k = 0; k < N; ++k) {
@@ -225,6 +230,7 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
         if ((e = hipMalloc(&f->d_hperm, hp.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
         if ((e = hipMemcpy(f->d_hperm, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
             return bail(e, "hipMemcpy(spectrum)");
+        f->d_wtab = f->d_hperm + (size_t)2 * N * fft_parts;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 6);
@@ -273,6 +279,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.out = d_out;
         fa.hist = f->d_hist[f->cur];
         fa.hperm = f->d_hperm;
+        fa.wtab = f->d_wtab;
         fa.n = (long long)n;
         fa.in_stride = (long long)in_stride;
         fa.out_stride = (long long)out_stride;
@@ -702,6 +709,7 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.out = d_out;
     fa.hist = f->d_hist[f->cur];
     fa.hperm = f->d_hperm;
+    fa.wtab = f->d_wtab;
     fa.n = (long long)(blocks * g->block_size);
     fa.in_stride = fa.out_stride = fa.n;
     fa.channels = 1;

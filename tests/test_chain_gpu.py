@@ -264,4 +264,6 @@ def test_config5_sharding_recipe_on_one_gpu(world):
     parts = [produce(*p) for p in plan]
     got = np.concatenate(parts)
     assert got.shape == whole.shape
-    assert rel_err(got, whole) <= 1e-6
+    # two fp32 results whose tiles fall at different offsets: each is within ~6e-7 of the
+    # exact answer, so they may differ from one another by twice that
+    assert rel_err(got, whole) <= 3e-6
