@@ -45,15 +45,15 @@ WORKLOADS = {
            "(BASELINE configs[2])", True, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 26, 1),
     "c3real": ("4095-tap bandpass on 2^27 real samples (partitioned overlap-save), in-memory",
                False, lambda S: S.fir_bandpass(4095, 0.1, 0.2), 27, 1),
-    "c4": ("64 channels x 2^22 real samples, hilbert 127 taps (BASELINE configs[3] first stage)",
-           False, lambda S: S.hilbert(127), 22, 64),
+    "c4": ("64 channels x 2^24 real samples, hilbert 127 taps (BASELINE configs[3] first stage)",
+           False, lambda S: S.hilbert(127), 24, 64),
     "lp31": ("31-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(31, 0.1), 28, 1),
     "lp15": ("15-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(15, 0.1), 28, 1),
     "lp63r": ("63-tap lowpass on 2^28 real samples, in-memory", False, lambda S: S.fir_lowpass(63, 0.1), 28, 1),
     "lp255": ("255-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(255, 0.1), 28, 1),
     # fused chains (sdr_chain_*): handled by bench_chain() below
-    "c4chain": ("64 channels x 2^22 real samples, hilbert(127, delay skip) + lowpass(127) fused in one pass "
-                "(BASELINE configs[3])", False, None, 22, 64),
+    "c4chain": ("64 channels x 2^24 real samples, hilbert(127, delay skip) + lowpass(127) fused in one pass "
+                "(BASELINE configs[3])", False, None, 24, 64),
     "c5": ("fused gen(sine) -> hilbert(127) -> lowpass(127): 2^29 real outputs per GPU, samples synthesised inside "
            "the FIR kernel (BASELINE configs[4], per-GPU share)", False, None, 29, 1),
 }
@@ -68,8 +68,11 @@ def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
     stream = torch.cuda.current_stream().cuda_stream
     if args.workload == "c4chain":
         # channel c of the global set: sine at f = (c+1)/160 cycles/sample
-        t = torch.arange(n, device=dev, dtype=torch.float32)
-        x = torch.stack([torch.sin(2 * np.pi * ((rank * channels + c) % 64 + 1) / 160.0 * t) for c in range(channels)])
+        t = torch.arange(n, device=dev, dtype=torch.float64)
+        x = torch.empty((channels, n), dtype=torch.float32, device=dev)
+        for c in range(channels):
+            x[c] = torch.sin(2 * np.pi * ((rank * channels + c) % 64 + 1) / 160.0 * t).to(torch.float32)
+        del t
         y = torch.empty_like(x)
 
         def step():

@@ -72,7 +72,7 @@ __device__ __forceinline__ float wave_real(int waveform, float arg) {
         case 2: return fract_f(arg) < 0.5f ? 1.0f : -1.0f; // oscillators.hpp:64-73
         case 3: {
             // :107-116, 1 - |4 fract(x + 0.25) - 2| as the reference's release build
-            // evaluates it: 4 (x - floor(x + 0.25)) - 1 (see oracle/sdr_oracle.c)
+            // evaluates it: 4 (x - floor(x + 0.25)) - 1 (pinned by tests/golden/gen.npz)
             const float fl = floorf(arg + 0.25f);
             const float d = arg - fl;
             const float t = 4.0f * d;

@@ -77,6 +77,23 @@ def test_compute_fails_loudly_without_gpu():
     assert p.returncode == 255 and b"no HIP device" in p.stderr
 
 
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing that ships -- the Python package, the HIP
+    library's sources, the blocks, the public header -- may import, link, open or name it."""
+    import glob
+    import re
+    files = []
+    for pat in ("sdr_amd/**/*.py", "sdr_amd/csrc/*", "blocks/*.cpp", "blocks/host/*", "blocks/Makefile", "include/*.h"):
+        files += [f for f in glob.glob(os.path.join(ROOT, pat), recursive=True) if os.path.isfile(f)]
+    assert len(files) > 15
+    for f in files:
+        text = open(f, errors="replace").read()
+        assert not re.search(r"oracle|sdro_|_ref/", text), f
+    # and the built library links nothing of it
+    out = subprocess.run(["ldd", sdr_amd._capi.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
 def run_block(name, args, stdin=b""):
     # argv[0] as the reference fixtures have it: ./NAME
     return subprocess.run(["./" + name] + args, input=stdin, capture_output=True, cwd=BIN)
