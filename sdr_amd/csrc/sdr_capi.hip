@@ -189,7 +189,8 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
         return rc;
     };
     if (guard.err != hipSuccess) return bail(guard.err, "hipSetDevice");
-    if ((e = prepare_kernel(*k, nchunks)) != hipSuccess) return bail(e, "tap count too large for the direct-form kernel");
+    if (!use_fft && (e = prepare_kernel(*k, nchunks)) != hipSuccess)
+        return bail(e, "tap count too large for the direct-form kernel");
     const size_t hist_bytes = channels * (size_t)f->hist_len * f->w * sizeof(float);
     if ((e = hipMalloc(&f->d_taps, g.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(taps)");
     if ((e = hipMalloc(&f->d_hist[0], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");

@@ -95,6 +95,22 @@ def test_partitioned_long_filters(ntaps):
     assert rel_err(y, O.fir(taps, x)) <= TOL
 
 
+@pytest.mark.parametrize("ntaps,n", [(40001, 30000), (131072, 12000)])
+def test_very_long_filters(ntaps, n):
+    """Tens of partitions, up to the library's limit of 64 (131072 taps): the history is longer
+    than the calls that feed it."""
+    rng = np.random.default_rng(ntaps)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps)).astype(np.float32)
+    x = rand(rng, n, False)
+    st = sdr_amd.FirState(taps, False)
+    assert "fft" in st.kernel_name
+    cut = n // 3
+    y = np.concatenate([sdr_amd.fir(st, x[:cut]), sdr_amd.fir(st, x[cut:cut + 5]), sdr_amd.fir(st, x[cut + 5:])])
+    assert rel_err(y, O.fir(taps, x)) <= TOL
+    with pytest.raises(sdr_amd.SdrError):
+        sdr_amd.FirState(np.ones(131073 + 2048, np.float32), False)   # 65 partitions: refused, not mis-filtered
+
+
 @pytest.mark.parametrize("grid", [3, 7, 0])
 @pytest.mark.parametrize("ntaps,cplx", [(4095, True), (4095, False), (2050, False), (3001, True)])
 def test_two_partition_spectrum_cache(monkeypatch, ntaps, cplx, grid):
