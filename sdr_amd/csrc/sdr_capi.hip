@@ -274,6 +274,13 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
     const size_t wbytes = f->w * sizeof(float);
     if (((uintptr_t)d_in % wbytes) || ((uintptr_t)d_out % wbytes))
         return fail(SDR_ERR_INVALID, "sdr_fir_process_device: buffers must be aligned to the sample size");
+    {
+        // tiles re-read their neighbours' inputs (halo): filtering in place would feed outputs back in
+        const uintptr_t i0 = (uintptr_t)d_in, o0 = (uintptr_t)d_out;
+        const uintptr_t i1 = i0 + ((f->channels - 1) * in_stride + n) * wbytes;
+        const uintptr_t o1 = o0 + ((f->channels - 1) * out_stride + n) * wbytes;
+        if (i0 < o1 && o0 < i1) return fail(SDR_ERR_INVALID, "sdr_fir_process_device: in and out overlap");
+    }
     if (f->use_fft) {
         FftArgs fa = {};
         fa.in = d_in;

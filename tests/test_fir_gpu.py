@@ -284,3 +284,15 @@ def test_linearity_and_impulse_full_size():
         assert float((seg[:, 1] + 2.0 * t).abs().max()) <= 2 * atol, p
     # nothing leaks between the impulses (no sample dropped, duplicated or moved)
     assert float(y.abs().sum()) == pytest.approx(float(len(pos) * 3.0 * t.abs().sum()), rel=2e-3)
+
+
+def test_in_place_is_refused():
+    """Tiles re-read their neighbours' inputs: the ABI says in and out must not overlap, and
+    the library checks rather than filter its own outputs."""
+    import torch
+    st = sdr_amd.FirState(sdr_amd.fir_lowpass(127, 0.1), False)
+    x = torch.zeros(100000, dtype=torch.float32, device="cuda")
+    with pytest.raises(sdr_amd.SdrError, match="overlap"):
+        st.process_device(x.data_ptr(), 50000, x.data_ptr() + 4 * 1000)
+    st.process_device(x.data_ptr(), 50000, x.data_ptr() + 4 * 50000)   # adjacent is fine
+    torch.cuda.synchronize()
