@@ -100,9 +100,9 @@ int main(int argc, char* argv[]) {
     const int kind = mode.as_choice();
     const bool no_source = unit.as_choice() != 3;
     const bool quadrature = kind == SDR_COMPLEX && waveform.as_choice() > SDR_WAVE_SINE;
-    if (quadrature && (hilbert_taps.as_uint() < 5 || hilbert_taps.as_uint() > (1u << 20))) {
+    if (quadrature && (hilbert_taps.as_uint() < 5 || hilbert_taps.as_uint() > SDR_MAX_TAPS)) {
         // the reference's tap design is 0/0 below 5 taps (all-NaN quadrature)
-        std::cerr << "error: gen: hilbert_taps must be between 5 and 1048576" << std::endl;
+        std::cerr << "error: gen: hilbert_taps must be between 5 and 131072" << std::endl;
         return -1;
     }
     if (sdr_device_count() < 1) {

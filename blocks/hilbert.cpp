@@ -30,8 +30,8 @@ int main(int argc, char* argv[]) {
         return -1;
     }
     const uint64_t ntaps = taps.as_uint();
-    if (ntaps < 5 || ntaps > (1u << 20)) {
-        std::cerr << "error: hilbert: taps must be between 5 and 1048576" << std::endl;
+    if (ntaps < 5 || ntaps > SDR_MAX_TAPS) {
+        std::cerr << "error: hilbert: taps must be between 5 and 131072" << std::endl;
         return -1;
     }
 

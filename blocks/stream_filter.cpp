@@ -107,8 +107,8 @@ int main(int argc, char* argv[]) {
     }
 
     const uint64_t ntaps = taps.as_uint();
-    if (ntaps < 2 || ntaps > (1u << 20)) {
-        std::cerr << "error: stream_filter: taps must be between 2 and 1048576" << std::endl;
+    if (ntaps < 2 || ntaps > SDR_MAX_TAPS) {
+        std::cerr << "error: stream_filter: taps must be between 2 and 131072" << std::endl;
         return -1;
     }
     if (!cutoff.is_set()) {

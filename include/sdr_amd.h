@@ -53,6 +53,9 @@ int sdr_hilbert_taps(float* taps, size_t n);
  * Frequencies are normalised (Hz / sample_rate); f2 only for band kinds. */
 int sdr_fir_design(int kind, float* taps, size_t n, float f1, float f2);
 
+/* Longest filter: 64 partitions of 2048 taps in the partitioned fast convolution. */
+#define SDR_MAX_TAPS 131072
+
 /* Streaming FIR ----------------------------------------------------------- */
 /* Replaces the kfr::fir_state<T,U> constructor (reference
  * libs/kfr/dsp/fir.hpp:57-68; blocks/hilbert.cpp:45, blocks/gen.cpp:138):

@@ -110,7 +110,7 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     if (!out) return fail(SDR_ERR_INVALID, "sdr_fir_create: out is NULL");
     *out = nullptr;
     if (!taps || ntaps == 0) return fail(SDR_ERR_INVALID, "sdr_fir_create: no taps");
-    if (ntaps > (1u << 20)) return fail(SDR_ERR_INVALID, "sdr_fir_create: too many taps");
+    if (ntaps > SDR_MAX_TAPS) return fail(SDR_ERR_INVALID, "sdr_fir_create: more than SDR_MAX_TAPS (131072) taps");
     if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
         return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
     if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
@@ -684,7 +684,7 @@ extern "C" int sdr_gen_set_hilbert(sdr_gen_t* g, size_t hilbert_taps, int prerol
     clear_error();
     if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: NULL handle");
     if (g->prerolled || g->quad) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: the generator has already produced samples");
-    if (hilbert_taps < 5 || hilbert_taps > (1u << 20)) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: taps must be 5..2^20");
+    if (hilbert_taps < 5 || hilbert_taps > SDR_MAX_TAPS) return fail(SDR_ERR_INVALID, "sdr_gen_set_hilbert: taps must be 5..131072");
     g->hilbert_taps = hilbert_taps;
     g->preroll = preroll != 0;
     return SDR_OK;
