@@ -43,7 +43,7 @@
 #define SDR_ST_NT 1
 #endif
 #ifndef SDR_SPREAD
-#define SDR_SPREAD 1
+#define SDR_SPREAD 2
 #endif
 
 namespace sdr_amd {
@@ -208,9 +208,11 @@ struct LaneConstsT {
 // everyone must be done before this one writes.  After an INVERSE transform no barrier is
 // needed here: past its block barrier every wave only reads its own columns (stage A'),
 // and the writes below touch only the writer's own columns.
-template <class Consts, class Hook>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <class Consts, class Hook, class HookB = NoHook, class HookR = NoHook>
 __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const Consts& c, Hook&& after_points_left,
-                                             bool after_forward = false) {
+                                             bool after_forward = false, HookB&& after_stage_b = HookB{},
+                                             HookR&& after_b_reads = HookR{}) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
     // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
@@ -225,12 +227,14 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     // ---- B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) --------------
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
+    after_b_reads();
     dft16<false>(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.tb(k));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
+    after_stage_b();
     __builtin_amdgcn_wave_barrier();
     // ---- C: lane (k0, k1 = l16), over n0 -> k2 ------------------------------------
 #pragma unroll
@@ -242,8 +246,9 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
 // y[256 n2 + tid] left at w[P16(n2)].
 // `before_barrier` runs after the last group-local write, ahead of the block barrier (a
 // slot for a share of the next tile's loads).
-template <class Consts, class Hook>
-__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const Consts& c, Hook&& before_barrier) {
+template <class Consts, class Hook, class HookC = NoHook, class HookR = NoHook>
+__device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, const Consts& c, Hook&& before_barrier,
+                                             HookC&& after_stage_c = HookC{}, HookR&& after_b_reads = HookR{}) {
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW;
     // ---- C': over k2 -> n0 --------------------------------------------------------
@@ -251,10 +256,12 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) row1[l16 * 17 + n0] = w[P16(n0)];
+    after_stage_c();
     __builtin_amdgcn_wave_barrier();
     // ---- B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 ----------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = row1[k * 17 + l16];
+    after_b_reads();
 #pragma unroll
     for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.tb(k));
     dft16<true>(w);
@@ -474,16 +481,25 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[P16(k)] = v[k];
         } else {
-            // the next tile's 16 loads go out in three shares spread over this tile's phases
-            // (5 rows here, 5 after the forward transform, 6 inside the inverse): the memory
-            // system sees a steadier request stream than one burst per tile (+2 %)
-            forward_tile(v, lds, tid, c, [&] {
-                if constexpr (!GEN) {
-                    if constexpr (SPREAD) load_rows(pn, nx, IC<0>{}, IC<5>{});
-                    else load(pn, nx);
-                }
-            }, after_forward);
-            if constexpr (!GEN && SPREAD) load_rows(pn, nx, IC<5>{}, IC<10>{});
+            // The next tile's 16 row loads go out in shares spread over this tile's phases: the
+            // memory system sees a steadier request stream than one burst per tile.  Share
+            // boundaries per SDR_SPREAD level (slots: A hook, B reads, B hook, after forward,
+            // after the pointwise product, C' hook, B' reads, before the inverse's barrier).
+            constexpr int LV = SPREAD ? SDR_SPREAD : 0;
+            constexpr int S0 = 0;
+            constexpr int S1 = LV == 3 ? 2 : LV == 2 ? 3 : LV == 1 ? 5 : 16; // after the A hook
+            constexpr int S2 = LV == 3 ? 4 : S1;                              // after B reads
+            constexpr int S3 = LV == 3 ? 6 : LV == 2 ? 6 : S2;                // after the B hook
+            constexpr int S4 = LV == 3 ? 8 : LV == 2 ? 9 : LV == 1 ? 10 : 16; // after forward
+            constexpr int S5 = LV == 3 ? 10 : LV == 2 ? 11 : S4;              // after the product
+            constexpr int S6 = LV == 3 ? 12 : LV == 2 ? 14 : S5;              // after the C' hook
+            constexpr int S7 = LV == 3 ? 14 : S6;                             // after B' reads
+            auto share = [&](auto lo, auto hi) {
+                if constexpr (!GEN && decltype(lo)::value < decltype(hi)::value) load_rows(pn, nx, lo, hi);
+            };
+            forward_tile(v, lds, tid, c, [&] { share(IC<S0>{}, IC<S1>{}); }, after_forward,
+                         [&] { share(IC<S2>{}, IC<S3>{}); }, [&] { share(IC<S1>{}, IC<S2>{}); });
+            share(IC<S3>{}, IC<S4>{});
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
             if (CACHE) {
@@ -504,7 +520,9 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
                     }
                 }
             }
-            inverse_tile(w, lds, tid, c, [&] { if constexpr (!GEN && SPREAD) load_rows(pn, nx, IC<10>{}, IC<16>{}); });
+            share(IC<S4>{}, IC<S5>{});
+            inverse_tile(w, lds, tid, c, [&] { share(IC<S7>{}, IC<16>{}); }, [&] { share(IC<S5>{}, IC<S6>{}); },
+                         [&] { share(IC<S6>{}, IC<S7>{}); });
         }
         float* q0 = a.out + (cur.ch * a.out_stride + first_out(cur) - HALO) * W; // &y[-halo] of the tile
 #pragma unroll
