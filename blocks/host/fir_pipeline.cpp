@@ -262,9 +262,13 @@ int FirPipeline::run(int in_fd, int out_fd) {
             if (cur->raw.size() + h.size > (64u << 20))
                 if ((rc = flush(false))) break;
             Item it{h, false, cur->raw.size(), 0};
-            cur->raw.resize(it.offset + h.size);
+            if (!cur->raw.resize(it.offset + h.size)) {
+                std::cerr << "error: out of memory forwarding a " << h.size << "-byte packet" << std::endl;
+                rc = -1;
+                break;
+            }
             it.count = rd.read_payload(cur->raw.data() + it.offset, h.size);
-            cur->raw.resize(it.offset + it.count);
+            (void)cur->raw.resize(it.offset + it.count);
             cur->items.push_back(it);
         } else {
             const bool cplx = h.content == kComplexSignal;

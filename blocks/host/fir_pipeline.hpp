@@ -18,6 +18,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/sdr_amd.h"
@@ -42,6 +43,38 @@ struct PipelineConfig {
     void* select_ctx = nullptr;
 };
 
+// Growable byte buffer that does not zero what it grows by (a std::vector would write every
+// forwarded payload byte once more before the read overwrites it).
+class RawBytes {
+public:
+    RawBytes() = default;
+    RawBytes(const RawBytes&) = delete;
+    RawBytes& operator=(const RawBytes&) = delete;
+    RawBytes(RawBytes&& o) noexcept : p_(o.p_), size_(o.size_), cap_(o.cap_) { o.p_ = nullptr; o.size_ = o.cap_ = 0; }
+    ~RawBytes() { std::free(p_); }
+    size_t size() const { return size_; }
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    void clear() { size_ = 0; }
+    // false when memory runs out (size unchanged)
+    bool resize(size_t n) {
+        if (n > cap_) {
+            size_t cap = cap_ ? cap_ : (1u << 20);
+            while (cap < n) cap *= 2;
+            void* q = std::realloc(p_, cap);
+            if (!q) return false;
+            p_ = static_cast<uint8_t*>(q);
+            cap_ = cap;
+        }
+        size_ = n;
+        return true;
+    }
+
+private:
+    uint8_t* p_ = nullptr;
+    size_t size_ = 0, cap_ = 0;
+};
+
 class FirPipeline {
 public:
     explicit FirPipeline(const PipelineConfig& cfg);
@@ -59,7 +92,7 @@ private:
     struct Batch {
         float* in = nullptr;  // pinned
         float* out = nullptr; // pinned
-        std::vector<uint8_t> raw;
+        RawBytes raw; // payloads of the forwarded packets, in arrival order
         std::vector<Item> items;
         size_t samples = 0;
         size_t cap_bytes = 0; // size of `in` and of `out`

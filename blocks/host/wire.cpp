@@ -68,6 +68,54 @@ void widen_pipe(int fd) {
 #endif
 }
 
+bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, void*), void* ctx) {
+    widen_pipe(in_fd);
+    widen_pipe(out_fd);
+    std::vector<uint8_t> buf(4u << 20);
+    GatherWriter out(out_fd);
+    size_t end = 0;          // valid bytes in buf
+    uint64_t payload_left = 0; // bytes of the current packet's payload still to come
+    bool forwarding = false;   // ... and whether they are forwarded
+    bool ok = true;
+    for (;;) {
+        ssize_t r = ::read(in_fd, buf.data() + end, buf.size() - end);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break; // end of stream (a partial header in buf[0, end) is dropped)
+        end += static_cast<size_t>(r);
+        size_t pos = 0, run = 0; // buf[run, pos) = forwarded bytes not yet handed to the writer
+        auto close_run = [&](size_t upto) {
+            if (forwarding && upto > run) out.add(buf.data() + run, upto - run);
+        };
+        while (pos < end) {
+            if (payload_left) {
+                const size_t take = static_cast<size_t>(std::min<uint64_t>(payload_left, end - pos));
+                pos += take;
+                payload_left -= take;
+                continue;
+            }
+            if (end - pos < sizeof(PacketHeader)) break;
+            PacketHeader h;
+            std::memcpy(&h, buf.data() + pos, sizeof h);
+            const bool f = forwards(h, ctx);
+            if (f != forwarding) {
+                close_run(pos);
+                forwarding = f;
+                run = pos;
+            }
+            pos += sizeof h;
+            payload_left = h.size;
+        }
+        close_run(pos);
+        if (!out.flush()) { ok = false; break; }
+        // keep the partial header (fewer than 16 bytes) for the next read
+        const size_t rest = end - pos;
+        if (rest) std::memmove(buf.data(), buf.data() + pos, rest);
+        end = rest;
+        // (the run restarts at the buffer's start: what is forwarded next is new data)
+    }
+    return ok;
+}
+
 PacketReader::PacketReader(int fd) : fd_(fd), buf_(1u << 20) { widen_pipe(fd); }
 
 size_t PacketReader::fetch(void* dst, size_t bytes) {

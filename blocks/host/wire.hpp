@@ -52,6 +52,15 @@ bool input_ready(int fd);
 // headers and payloads are served from that buffer -- with ~8 KiB packets a system call
 // per header and per payload is what bounds a block's throughput otherwise.  A refill
 // never waits for more than the first byte, so an interactive pipe sees no added latency.
+// Packet routing without touching payloads (the reference's Source::pass / Source::drop,
+// lib/sdr/stream.cpp:219-364, which splice packet by packet): the stream is read in large
+// pieces, headers are parsed in place, and every run of consecutive forwarded packets leaves
+// in ONE gathered write straight from the read buffer -- two copies per byte but a few
+// system calls per megabyte instead of three per packet.  A short final payload is forwarded
+// as far as it arrived, behind its unchanged header; a short final header ends the stream.
+// Returns false if a write failed.
+bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, void*), void* ctx);
+
 class PacketReader {
 public:
     explicit PacketReader(int fd = 0);

@@ -90,19 +90,9 @@ int main(int argc, char* argv[]) {
     Rule rule{mode.as_choice() == 1, &ids, &content};
 
     if (!fir.is_set() || fir.as_choice() < 0) {
-        // the reference block: pure packet routing on the host
-        host::PacketReader rd(0);
-        host::PacketWriter wr(1);
-        std::vector<uint8_t> payload;
-        while (rd.next()) {
-            const host::PacketHeader h = rd.header();
-            if (!rule.forwards(h)) continue;
-            payload.resize(h.size);
-            const size_t got = rd.read_payload(payload.data(), h.size);
-            (void)host::write_full(1, &h, sizeof h);
-            (void)host::write_full(1, payload.data(), got);
-        }
-        wr.flush_to_disk();
+        // the reference block: pure packet routing on the host, payloads never looked at
+        (void)host::route_packets(0, 1, forward_cb, &rule);
+        host::PacketWriter(1).flush_to_disk();
         return 0;
     }
 

@@ -14,6 +14,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle_lib as O
 import sdr_amd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -154,3 +155,50 @@ def test_stream_filter_truncated_and_empty_input():
     pkt = HDR.pack(1, 0, 100, 7) + b"x" * 40
     p = run_block("stream-filter", ["pass"], pkt)
     assert p.stdout == pkt
+
+
+def test_stream_filter_routing_in_dribbles_and_bulk():
+    """The routing loop parses headers in place in whatever pieces the pipe delivers: a stream
+    fed 7 bytes at a time (headers split across reads), one fed in bulk with payloads of every
+    size from empty to larger than a read, and a truncated tail; against the predicate of
+    the oracle's restatement of blocks/stream_filter.cpp:59-86."""
+    import random
+    rng = random.Random(5)
+    sizes = [0, 1, 15, 16, 17, 8176, 70000, 3, 0, 0, 5000000, 8, 4096] + [rng.randrange(0, 3000) for _ in range(300)]
+    packets = []
+    for i, n in enumerate(sizes):
+        pid, content = rng.randrange(0, 6), rng.randrange(0, 10)
+        packets.append((pid, content, HDR.pack(pid, content, n, i) + bytes([i % 251]) * n))
+    stream = b"".join(p[2] for p in packets)
+    for args, mode, ids, contents in (
+            (["pass", "1,3"], "pass", {1, 3}, None), (["drop", "2", "signal,binary"], "drop", {2}, {6, 0}),
+            (["pass", "content=complex_signal"], "pass", None, {7}), (["drop"], "drop", None, None), (["pass"], "pass", None, None)):
+        want = b"".join(p[2] for p in packets if O.stream_filter_forward(mode, ids, contents, p[0], p[1]))
+        got = run_block("stream-filter", args, stream)
+        assert got.returncode == 0 and got.stdout == want, args
+        # the same cut short inside a payload, and inside a header
+        for cut in (len(stream) - 700, len(packets[0][2]) + 5):
+            want_cut = b""
+            pos = 0
+            for p in packets:
+                part = stream[pos:min(cut, pos + len(p[2]))]
+                pos += len(p[2])
+                if len(part) >= 16 and O.stream_filter_forward(mode, ids, contents, p[0], p[1]):
+                    want_cut += part
+                if pos >= cut:
+                    break
+            assert run_block("stream-filter", args, stream[:cut]).stdout == want_cut, (args, cut)
+    # 7 bytes at a time through a real pipe
+    small = b"".join(p[2] for p in packets[13:60])
+    want = b"".join(p[2] for p in packets[13:60] if O.stream_filter_forward("pass", {1, 3}, None, p[0], p[1]))
+    proc = subprocess.Popen(["./stream-filter", "pass", "1,3"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, cwd=BIN)
+    import threading
+    out = []
+    t = threading.Thread(target=lambda: out.append(proc.stdout.read()))
+    t.start()
+    for i in range(0, len(small), 7):
+        proc.stdin.write(small[i:i + 7])
+        proc.stdin.flush()
+    proc.stdin.close()
+    t.join()
+    assert proc.wait() == 0 and out[0] == want
