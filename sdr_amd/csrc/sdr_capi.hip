@@ -140,19 +140,21 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     int fft_halo = 0, fft_parts = 1;
     fir_fft_plan(ntaps, &fft_halo, &fft_parts);
     // Measured crossover (profiles/r01_direct_vs_fft_crossover.txt): the direct form holds
-    // its memory-bound floor (5.7 TB/s) up to 32 dense taps (40 on real samples) or ~95
+    // its memory-bound floor (5.7-6.0 TB/s) up to 32 dense taps (40 on real samples) or ~87
     // Hilbert-structured taps; from there the fast convolution is quicker.
-    const size_t fft_from = stride == 2 ? 96u : sample_kind == SDR_COMPLEX ? 33u : 41u;
+    const size_t fft_from = stride == 2 ? 88u : sample_kind == SDR_COMPLEX ? 33u : 41u;
     bool use_fft = ntaps >= fft_from && fft_parts <= 64;
     if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_parts <= 64;
 
-    int R = env_int("SDR_AMD_R", 8);
+    // compacted taps g[i] = h[stride*i + shift], zero-padded to whole chunk pairs
+    const size_t kept = (ntaps - shift + stride - 1) / stride;
+    // Outputs per lane: 4 (8 KB tiles, more workgroups in flight: 5.9-6.0 TB/s) while the filter
+    // is short enough to stay memory-bound that way, else 8 (profiles/r01_direct_r_sweep.txt)
+    int R = env_int("SDR_AMD_R", kept <= 31 ? 4 : 8);
     if (R != 4 && R != 8 && R != 16) return fail(SDR_ERR_INVALID, "SDR_AMD_R must be 4, 8 or 16");
     const KernelInfo* k = find_kernel(R, stride, sample_kind == SDR_REAL);
     if (!k) return fail(SDR_ERR_INVALID, "sdr_fir_create: no kernel for this configuration");
 
-    // compacted taps g[i] = h[stride*i + shift], zero-padded to whole chunk pairs
-    const size_t kept = (ntaps - shift + stride - 1) / stride;
     const size_t span = (kept - 1) * stride + 1; // sample offsets covered
     int nchunks = (int)((span + R - 1) / R);
     nchunks += nchunks & 1;
