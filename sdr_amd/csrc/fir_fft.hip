@@ -734,6 +734,11 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     long long grid_int = 0;
     if (inner > 0) {
         const long long total = inner * a.channels;
+        // a short call: at least two tiles per workgroup (its set-up costs about one), down to
+        // the third of the grid that is resident at once
+        long long cap = total / 2 > grid_blocks / 3 ? total / 2 : grid_blocks / 3;
+        if (cap < 1) cap = 1;
+        if (cap < grid_blocks) grid_blocks = (int)cap;
         const long long rounds = (total + grid_blocks - 1) / grid_blocks;
         grid_int = (total + rounds - 1) / rounds;
     }

@@ -236,7 +236,9 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
         f->d_wtab = f->d_hperm + (size_t)2 * N * fft_parts;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 6);
+        // three workgroups are resident per CU (two for the partitioned variants); three rounds of
+        // them leave a shorter tail than two (same-box sweep: 9 per CU 1 % ahead of 6, 12 and 16 level)
+        f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 9);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
         f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", f->fft_grid));
         f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
