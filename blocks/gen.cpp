@@ -11,10 +11,14 @@
 // 167-176) it runs until that input ends, retuning at packet boundaries.  Samples are
 // produced a few packets per GPU round trip, so a retune takes effect within that many
 // packets (the reference: within one).
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -137,37 +141,94 @@ int main(int argc, char* argv[]) {
     }
     host::widen_pipe(1);
     float current = cps;
-    const size_t blocks_per_call = no_source ? 512 : 4; // ~4 MiB per round trip; short when retunable
-    uint8_t* buf = static_cast<uint8_t*>(sdr_host_alloc(blocks_per_call * block * elt));
-    if (!buf) {
+    size_t blocks_per_call = no_source ? 512 : 4; // ~4 MiB per round trip; short when retunable
+    if (const char* e = std::getenv("SDR_AMD_GEN_BLOCKS")) blocks_per_call = std::max(1, std::atoi(e));
+    // two pinned buffers: with a fixed frequency a producer thread fills one on the GPU while
+    // the main thread writes the other to the pipe
+    uint8_t* bufs[2] = {static_cast<uint8_t*>(sdr_host_alloc(blocks_per_call * block * elt)),
+                        no_source ? static_cast<uint8_t*>(sdr_host_alloc(blocks_per_call * block * elt)) : nullptr};
+    if (!bufs[0] || (no_source && !bufs[1])) {
         std::cerr << "error: gen: " << sdr_last_error() << std::endl;
         return -1;
     }
-    for (;;) {
-        if (!no_source && freq_msg_set.exchange(false, std::memory_order_acq_rel)) {          // :167-176
-            if (source_end.load(std::memory_order_relaxed)) break;
-            const float msg = freq_msg.load(std::memory_order_relaxed);
-            if (msg != current) {
-                current = msg;
-                sdr_gen_set_frequency(g, current);
-            }
-        }
-        if (sdr_gen_generate(g, blocks_per_call, buf) != SDR_OK) {
-            std::cerr << "error: gen: " << sdr_last_error() << std::endl;
-            return -1;
-        }
+    auto write_packets = [&](const uint8_t* buf) {
         host::GatherWriter out(1);
         for (size_t b = 0; b < blocks_per_call; ++b) {
             out.add(&hdr, sizeof hdr);
             out.add(buf + b * block * elt, block * elt);
         }
-        if (!out.flush()) {
-            sdr_gen_destroy(g);
-            sdr_host_free(buf);
-            return 0; // output closed
+        return out.flush();
+    };
+    int rc = 0;
+    bool output_closed = false;
+    host::ignore_sigpipe();
+    if (no_source) {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool full[2] = {false, false};
+        bool stop = false, failed = false;
+        std::string error;
+        std::thread producer([&] {
+            for (int i = 0;; i ^= 1) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !full[i] || stop; });
+                    if (stop) return;
+                }
+                const bool ok = sdr_gen_generate(g, blocks_per_call, bufs[i]) == SDR_OK;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!ok) { failed = true; error = sdr_last_error(); }
+                    full[i] = true;
+                }
+                cv.notify_all();
+                if (!ok) return;
+            }
+        });
+        for (int i = 0;; i ^= 1) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return full[i]; });
+                if (failed) {
+                    std::cerr << "error: gen: " << error << std::endl;
+                    rc = -1;
+                    break;
+                }
+            }
+            if (!write_packets(bufs[i])) { output_closed = true; break; }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                full[i] = false;
+            }
+            cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        producer.join();
+    } else {
+        for (;;) {
+            if (freq_msg_set.exchange(false, std::memory_order_acq_rel)) {                        // :167-176
+                if (source_end.load(std::memory_order_relaxed)) break;
+                const float msg = freq_msg.load(std::memory_order_relaxed);
+                if (msg != current) {
+                    current = msg;
+                    sdr_gen_set_frequency(g, current);
+                }
+            }
+            if (sdr_gen_generate(g, blocks_per_call, bufs[0]) != SDR_OK) {
+                std::cerr << "error: gen: " << sdr_last_error() << std::endl;
+                rc = -1;
+                break;
+            }
+            if (!write_packets(bufs[0])) { output_closed = true; break; }
         }
     }
     sdr_gen_destroy(g);
-    sdr_host_free(buf);
-    return 0;
+    sdr_host_free(bufs[0]);
+    sdr_host_free(bufs[1]);
+    if (output_closed) host::die_of_sigpipe(); // the GPU is released; end like the reference does
+    return rc;
 }

@@ -195,7 +195,7 @@ void FirPipeline::writer_loop(int out_fd) {
                 out.add(zeros.data(), h.size);
             }
         }
-        (void)out.flush();
+        if (!out.flush()) output_closed_.store(true, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(mu_);
             free_.push_back(b);
@@ -254,7 +254,9 @@ int FirPipeline::run(int in_fd, int out_fd) {
         return 0;
     };
 
+    ignore_sigpipe();
     while (rd.next()) {
+        if (output_closed_.load(std::memory_order_relaxed)) break;
         const PacketHeader h = rd.header();
         if (!is_filtered(h)) {
             const bool fwd = cfg_.forward_other ? cfg_.forward_other(h, cfg_.forward_ctx) : true;
@@ -306,6 +308,7 @@ int FirPipeline::run(int in_fd, int out_fd) {
     }
     cv_.notify_all();
     writer_.join();
+    if (!rc && output_closed_.load()) rc = kOutputClosed;
     return rc;
 }
 

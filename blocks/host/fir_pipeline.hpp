@@ -13,6 +13,7 @@
 // interleaving on input.  A batch is flushed when full, when the content type
 // changes, when no more input is pending (latency), and at end of stream.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -80,6 +81,8 @@ public:
     explicit FirPipeline(const PipelineConfig& cfg);
     ~FirPipeline();
     // Runs until end of input.  Returns 0, or -1 after printing an error.
+    // 0 = end of input; kOutputClosed = the output went away (the caller ends by SIGPIPE); other = error
+    static constexpr int kOutputClosed = 141;
     int run(int in_fd, int out_fd);
 
 private:
@@ -122,6 +125,7 @@ private:
     std::condition_variable cv_;
     std::deque<Batch*> free_, ready_;
     bool done_ = false;
+    std::atomic<bool> output_closed_{false}; // a write failed (EPIPE): stop reading, release the GPU
     size_t skip_left_;
     std::thread writer_;
 };

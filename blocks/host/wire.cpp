@@ -4,6 +4,7 @@
 #include <cerrno>
 #include <fcntl.h>
 #include <poll.h>
+#include <csignal>
 #include <sys/uio.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -114,6 +115,14 @@ bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, 
         // (the run restarts at the buffer's start: what is forwarded next is new data)
     }
     return ok;
+}
+
+void ignore_sigpipe() { (void)::signal(SIGPIPE, SIG_IGN); }
+
+void die_of_sigpipe() {
+    (void)::signal(SIGPIPE, SIG_DFL);
+    (void)::raise(SIGPIPE);
+    ::_exit(141); // not reached unless SIGPIPE is blocked
 }
 
 PacketReader::PacketReader(int fd) : fd_(fd), buf_(1u << 20) { widen_pipe(fd); }

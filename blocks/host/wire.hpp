@@ -41,6 +41,12 @@ size_t read_full(int fd, void* dst, size_t size);
 bool write_full(int fd, const void* src, size_t size);
 // Best effort: a 1 MiB kernel buffer for a pipe end (no effect on other descriptors).
 void widen_pipe(int fd);
+// Blocks that hold GPU state: a closed output must not kill the process in the middle of GPU
+// work (tearing down a process with queues in flight costs the driver ~0.2 s).  SIGPIPE is
+// ignored while the block runs -- writes fail with EPIPE instead, the block releases the GPU --
+// and die_of_sigpipe() then ends the process the way the reference ends: killed by SIGPIPE.
+void ignore_sigpipe();
+[[noreturn]] void die_of_sigpipe();
 // True when a read on fd would not block right now (data or EOF pending).
 bool input_ready(int fd);
 

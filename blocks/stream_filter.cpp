@@ -117,6 +117,11 @@ int main(int argc, char* argv[]) {
     cfg.forward_ctx = &rule;
     if (const char* e = std::getenv("SDR_AMD_BATCH_BYTES")) cfg.batch_bytes = std::strtoull(e, nullptr, 0);
     if (const char* e = std::getenv("SDR_AMD_DEVICE")) cfg.device = std::atoi(e);
-    host::FirPipeline pipe(cfg);
-    return pipe.run(0, 1);
+    int rc;
+    {
+        host::FirPipeline pipe(cfg);
+        rc = pipe.run(0, 1);
+    } // (the GPU state is released here)
+    if (rc == host::FirPipeline::kOutputClosed) host::die_of_sigpipe(); // end like the reference: by SIGPIPE
+    return rc;
 }
