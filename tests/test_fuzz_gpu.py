@@ -2,6 +2,8 @@
 random tap counts (both kernel families and every halo / partition class), real and complex
 samples, 1..4 channels with padded strides, streams cut at random points (tile-sized, tiny and
 empty calls).  Bar: 1e-5 of the expected output's RMS, as everywhere."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,7 +21,12 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / np.sqrt(np.mean(np.abs(b) ** 2)))
 
 
-@pytest.mark.parametrize("seed", range(42))
+# SDR_FUZZ_SEEDS / SDR_FUZZ_MAXN widen the run (e.g. 400 seeds, streams up to 300000 samples)
+N_SEEDS = int(os.environ.get("SDR_FUZZ_SEEDS", "42"))
+MAX_N = int(os.environ.get("SDR_FUZZ_MAXN", "60000"))
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_streams(seed):
     import torch
     rng = np.random.default_rng(1000 + seed)
@@ -31,7 +38,7 @@ def test_random_streams(seed):
     taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
     if hilbert_like:
         taps[(ntaps // 2) % 2::2] = 0.0          # every other tap zero, like sdr::hilbert
-    n = int(rng.integers(1, 60000))
+    n = int(rng.integers(1, MAX_N))
     ncuts = int(rng.integers(0, 6))
     cuts = sorted(int(c) for c in rng.integers(0, n + 1, ncuts))
     bounds = [0] + cuts + [n]
