@@ -1,0 +1,74 @@
+"""Seeded differential fuzz of the fused chain (sdr_chain_*) against the oracle evaluated
+stage by stage: 1..4 stages of random length, each with a random group-delay skip (anything
+from none to all of its warm-up), real and complex samples, 1..3 channels, the stream cut at
+random points -- inside the start-of-stream region where the fused filter's outputs are
+patched with the staged ones, and far beyond it.  Bar: 1e-5 of the expected output's RMS."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import sdr_amd
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+N_SEEDS = int(os.environ.get("SDR_FUZZ_SEEDS", "60"))
+
+
+def staged_oracle(stages, x):
+    y = x
+    for taps, skip in stages:
+        y = O.fir(taps, y)[skip:]
+    return y
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_random_chains(seed):
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    nstages = int(rng.integers(1, 5))
+    stages = []
+    for _ in range(nstages):
+        nt = int(rng.integers(1, (400 if nstages < 3 else 130)))
+        taps = (rng.uniform(-1, 1, nt) * np.hanning(nt + 2)[1:-1]).astype(np.float32)
+        if nt >= 9 and rng.integers(0, 3) == 0:
+            taps[(nt // 2) % 2::2] = 0.0                      # Hilbert-like structure
+        skip = int(rng.integers(0, nt)) if rng.integers(0, 2) else (nt - 1) // 2
+        stages.append((taps, skip))
+    cplx = bool(rng.integers(0, 2))
+    C = int(rng.integers(1, 4))
+    total_skip = sum(s for _, s in stages)
+    n = int(rng.integers(total_skip + 1, 50000))
+    ncuts = int(rng.integers(0, 6))
+    lead = sum(len(t) for t, _ in stages) + 8
+    cuts = sorted(int(c) for c in np.concatenate([rng.integers(0, n + 1, ncuts),
+                                                   rng.integers(0, min(n, lead) + 1, int(rng.integers(0, 3)))]))
+    bounds = [0] + cuts + [n]
+    w = 2 if cplx else 1
+    x = rng.uniform(-1, 1, (C, n, w)).astype(np.float32)
+    chain = sdr_amd.Chain(stages, cplx, channels=C)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = [[] for _ in range(C)]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        m = b - a
+        if m == 0:
+            continue
+        d_in = torch.from_numpy(np.ascontiguousarray(x[:, a:b])).cuda()
+        d_out = torch.full((C, m, w), 777.0, dtype=torch.float32, device="cuda")
+        n_out = chain.process_device(d_in.data_ptr(), m, d_out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        assert 0 <= n_out <= m
+        o = d_out.cpu().numpy()
+        assert np.all(o[:, n_out:] == 777.0)                  # nothing written past the outputs
+        for c in range(C):
+            outs[c].append(o[c, :n_out])
+    for c in range(C):
+        xc = x[c].reshape(-1).view(np.complex64) if cplx else x[c].reshape(-1)
+        got = np.concatenate(outs[c]).reshape(-1)
+        got = got.view(np.complex64) if cplx else got
+        ref = staged_oracle(stages, xc)
+        assert got.shape == ref.shape, (seed, got.shape, ref.shape)   # n - sum(skips): nothing dropped or duplicated
+        rms = np.sqrt(np.mean(np.abs(ref.astype(np.complex128)) ** 2))
+        err = np.max(np.abs(got.astype(np.complex128) - ref.astype(np.complex128)))
+        assert err <= TOL * rms, (seed, [len(t) for t, _ in stages], [s for _, s in stages], cplx, C, bounds, float(err / rms))
