@@ -188,9 +188,11 @@ void sdr_gen_destroy(sdr_gen_t* g);
  * written to memory (the few packets that overlap the start-of-stream warm-up are
  * materialised once, in a buffer the first call allocates).  Same results as
  * sdr_gen_generate_device followed by sdr_chain_process_device.  Real generator,
- * real one-channel chain whose combined filter has >= 41 taps (>= 96 if every other tap is zero), packets of 256..2^23
- * samples; *n_out outputs are written from d_out (DEVICE memory), asynchronously on
- * hip_stream. */
+ * real one-channel chain, packets of 256..2^23 samples; *n_out outputs are written
+ * from d_out (DEVICE memory), asynchronously on hip_stream.  A chain short enough
+ * for the direct-form kernel is moved to the overlap-save kernels (where the
+ * generator lives) by its first call, which must then come before any
+ * sdr_chain_process_device on that chain (or after sdr_chain_reset). */
 int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t blocks, void* d_out, size_t* n_out,
                               void* hip_stream);
 

@@ -31,6 +31,7 @@ struct sdr_chain {
     std::vector<size_t> skip_left; // per stage, for the staged prefix
     sdr_fir_t* fused = nullptr;    // the single equivalent filter
     size_t fused_ntaps = 0;
+    std::vector<float> fused_taps; // kept to rebuild the fused filter on the overlap-save path (generate_device)
     size_t total_skip = 0; // D: outputs of the fused filter dropped at stream start
     size_t warm = 0;       // M0: leading chain outputs taken from the staged path
     size_t prefix = 0;     // P = M0 + D inputs go through the staged path too
@@ -79,6 +80,7 @@ extern "C" int sdr_chain_create(sdr_chain_t** out, size_t nstages, const float* 
     }
     std::vector<float> hf(h.begin(), h.end());
     c->fused_ntaps = hf.size();
+    c->fused_taps = hf;
     for (size_t k = 0; k < nstages; ++k) {
         const size_t d = skips ? skips[k] : 0;
         c->skips.push_back(d);
@@ -203,6 +205,18 @@ extern "C" int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t bl
                                          void* hip_stream) {
     if (n_out) *n_out = 0;
     if (!c || !g) return fail(SDR_ERR_INVALID, "sdr_chain_generate_device: NULL handle");
+    // The generator is fused into the overlap-save kernels only.  A chain whose fused filter is
+    // short enough for the direct form is moved over before its first sample (allocates once).
+    if (!sdr_amd::fir_uses_overlap_save(c->fused) && c->kind == SDR_REAL && c->channels == 1) {
+        if (c->pos != 0)
+            return fail(SDR_ERR_INVALID, "sdr_chain_generate_device: this short chain has already filtered samples through the "
+                                         "direct-form kernel; generate from the start of the stream (or after sdr_chain_reset)");
+        sdr_fir_t* f = nullptr;
+        int rc0 = sdr_amd::fir_create_overlap_save(&f, c->fused_taps.data(), c->fused_taps.size(), c->kind, c->channels, c->device);
+        if (rc0 != SDR_OK) return rc0;
+        sdr_fir_destroy(c->fused);
+        c->fused = f;
+    }
     int rc = sdr_amd::fir_generated_supported(c->fused, g);
     if (rc != SDR_OK) return rc;
     if (blocks == 0) return SDR_OK;

@@ -15,5 +15,10 @@ int fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, float* d_ou
 // SDR_OK when fir_process_generated would accept the pair, else the error (message set).
 int fir_generated_supported(const sdr_fir_t* f, const sdr_gen_t* g);
 size_t gen_block_size(const sdr_gen_t* g);
+// sdr_fir_create with the overlap-save path chosen whatever the tap count (the fused
+// generator lives in those kernels only); and which path a handle uses.
+int fir_create_overlap_save(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind, size_t channels,
+                            int device);
+bool fir_uses_overlap_save(const sdr_fir_t* f);
 
 } // namespace sdr_amd

@@ -104,8 +104,9 @@ static int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
-                              size_t channels, int device) {
+// force_path: -1 = choose by tap count (and SDR_AMD_FFT), 0 = direct form, 1 = overlap-save
+static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind, size_t channels,
+                           int device, int force_path) {
     clear_error();
     if (!out) return fail(SDR_ERR_INVALID, "sdr_fir_create: out is NULL");
     *out = nullptr;
@@ -145,6 +146,7 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     const size_t fft_from = stride == 2 ? 88u : sample_kind == SDR_COMPLEX ? 33u : 41u;
     bool use_fft = ntaps >= fft_from && fft_parts <= 64;
     if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_parts <= 64;
+    if (force_path >= 0) use_fft = force_path != 0 && fft_parts <= 64;
 
     // compacted taps g[i] = h[stride*i + shift], zero-padded to whole chunk pairs
     const size_t kept = (ntaps - shift + stride - 1) / stride;
@@ -252,6 +254,18 @@ extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, 
     *out = f;
     return SDR_OK;
 }
+
+extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                              size_t channels, int device) {
+    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, -1);
+}
+
+int sdr_amd::fir_create_overlap_save(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                                     size_t channels, int device) {
+    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, 1);
+}
+
+bool sdr_amd::fir_uses_overlap_save(const sdr_fir_t* f) { return f && f->use_fft; }
 
 extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (!f) return;

@@ -226,9 +226,19 @@ def test_generator_fusion_rejects_what_it_cannot_do():
     import torch
     out = torch.empty(4 * B, dtype=torch.float32, device="cuda")
     for g, ch in ((gen_c, sdr_amd.Chain(stages, False)), (gen_small, sdr_amd.Chain(stages, False)),
-                  (gen, sdr_amd.Chain(stages, False, channels=2)), (gen, sdr_amd.Chain([(sdr_amd.hilbert(31), 15)], False))):
+                  (gen, sdr_amd.Chain(stages, False, channels=2))):
         with pytest.raises(sdr_amd.SdrError):
             ch.generate_device(g, 2, out.data_ptr())
+    # a chain short enough for the direct-form kernel moves to the overlap-save kernels on its
+    # first generated packet -- unless it has already filtered samples the other way
+    short = sdr_amd.Chain([(sdr_amd.hilbert(31), 15)], False)
+    assert short.generate_device(gen, 2, out.data_ptr()) == 2 * B - 15
+    used = sdr_amd.Chain([(sdr_amd.hilbert(31), 15)], False)
+    used.process_tensor(torch.zeros(1000, dtype=torch.float32, device="cuda"))
+    with pytest.raises(sdr_amd.SdrError, match="already filtered"):
+        used.generate_device(gen, 2, out.data_ptr())
+    used.reset()
+    assert used.generate_device(sdr_amd.Gen("sine", False, 1.0, 0.1, 0.0, B), 2, out.data_ptr()) == 2 * B - 15
 
 
 @pytest.mark.parametrize("world", [2, 3])
