@@ -19,6 +19,49 @@
 #include "host/cli.hpp"
 #include "host/wire.hpp"
 
+namespace {
+
+// What one packet of the wrapped stream looks like, or why it cannot be built.
+struct Shape {
+    uint32_t bytes = 0;       // payload size
+    uint64_t nanoseconds = 0; // header duration
+    const char* problem = nullptr;
+};
+
+constexpr uint64_t kNsPerSecond = 1000000000ull;
+
+// The reference's sizing rules (blocks/wrap.cpp:60-88), as one function of the options:
+// an explicit element count wins; else a duration at a sample rate; else the block size the
+// generator would use.  A sample rate also fixes the duration written into every header.
+Shape packet_shape(uint64_t elt, bool has_count, uint64_t count, bool has_duration, uint64_t duration,
+                   bool has_rate, uint64_t rate) {
+    Shape sh;
+    sh.nanoseconds = duration;
+    uint64_t elements;
+    if (has_count) {
+        if (count == 0) { sh.problem = "element_count must be greater than zero"; return sh; }
+        elements = count;
+    } else if (has_rate && has_duration) {
+        elements = duration * rate / kNsPerSecond;
+        if (elements == 0) { sh.problem = "packet duration is too small"; return sh; }
+    } else {
+        elements = sdr_optimal_block_size(elt, rate);
+    }
+    sh.bytes = static_cast<uint32_t>(elt * elements);
+    if (has_rate) {
+        sh.nanoseconds = rate ? (sh.bytes / elt) * kNsPerSecond / rate : 0;
+        if (has_duration && has_count && duration != sh.nanoseconds) sh.problem = "duration and element_count do not match";
+    }
+    return sh;
+}
+
+int complain(const char* what) {
+    std::cerr << "error: wrap: " << what << std::endl;
+    return -1;
+}
+
+} // namespace
+
 int main(int argc, char* argv[]) {
     cli::Option content = cli::Option::choice("content_type", host::content_choices(), host::kBinary);
     cli::Option id = cli::Option::uint("stream", "ID", 0);
@@ -31,60 +74,39 @@ int main(int argc, char* argv[]) {
     if (!cli::parse(pos, kw, argc, argv, std::cerr)) return -1;
 
     if (!element_size.is_set()) {
-        std::cerr << "error: wrap: option 'element_size' is required" << std::endl;
+        complain("option 'element_size' is required");
         cli::usage(argv[0], pos, kw, std::cerr);
         return -1;
     }
-    if (element_size.as_uint() < 1) {
-        std::cerr << "error: wrap: element_size must be greater than zero" << std::endl;
-        return -1;
-    }
+    if (element_size.as_uint() == 0) return complain("element_size must be greater than zero");
     if (!cli::valid_stream_id(id.as_uint())) {
-        std::cerr << "error: gen: " << id.as_uint() << " is not a valid stream id" << std::endl; // sic (wrap.cpp:51)
+        // (the reference names `gen` in this message: blocks/wrap.cpp:51)
+        std::cerr << "error: gen: " << id.as_uint() << " is not a valid stream id" << std::endl;
         return -1;
     }
-    const uint64_t es = element_size.as_uint(), rate = sample_rate.as_uint(), dur = duration.as_uint();
-    host::PacketHeader hdr;
-    hdr.id = static_cast<uint16_t>(id.as_uint());
-    hdr.content = static_cast<uint16_t>(content.as_choice());
-    hdr.size = 0;
-    hdr.duration = dur;
-    if (element_count.is_set()) {                                               // wrap.cpp:60-79
-        if (element_count.as_uint() == 0) {
-            std::cerr << "error: wrap: element_count must be greater than zero" << std::endl;
-            return -1;
-        }
-        hdr.size = static_cast<uint32_t>(es * element_count.as_uint());
-    } else if (sample_rate.is_set() && duration.is_set()) {
-        const uint64_t count = dur * rate / 1000000000ull;
-        if (count < 1) {
-            std::cerr << "error: wrap: packet duration is too small" << std::endl;
-            return -1;
-        }
-        hdr.size = static_cast<uint32_t>(es * count);
-    } else {
-        hdr.size = static_cast<uint32_t>(es * sdr_optimal_block_size(es, rate));
-    }
-    if (sample_rate.is_set()) {                                                 // :81-88
-        hdr.duration = rate ? (hdr.size / es) * 1000000000ull / rate : 0;
-        if (duration.is_set() && element_count.is_set() && dur != hdr.duration) {
-            std::cerr << "error: wrap: duration and element_count do not match" << std::endl;
-            return -1;
-        }
-    }
+    const Shape shape = packet_shape(element_size.as_uint(), element_count.is_set(), element_count.as_uint(),
+                                     duration.is_set(), duration.as_uint(), sample_rate.is_set(), sample_rate.as_uint());
+    if (shape.problem) return complain(shape.problem);
     if (!content.is_set())
         std::cerr << "warning: wrap: content type not set, input will be treated as binary data" << std::endl;
 
-    std::vector<uint8_t> buf(hdr.size);
+    host::PacketHeader every;
+    every.id = static_cast<uint16_t>(id.as_uint());
+    every.content = static_cast<uint16_t>(content.as_choice());
+    every.size = shape.bytes;
+    every.duration = shape.nanoseconds;
+
+    // one read per packet; the last one may come up short and says so in its header
+    std::vector<uint8_t> payload(shape.bytes);
     host::PacketWriter sink(1);
-    for (;;) {
-        const size_t got = host::read_full(0, buf.data(), buf.size());
+    size_t got;
+    do {
+        got = host::read_full(0, payload.data(), payload.size());
         if (got == 0) break;
-        host::PacketHeader h = hdr;
+        host::PacketHeader h = every;
         h.size = static_cast<uint32_t>(got);
-        sink.send(h, buf.data());
-        if (got < buf.size()) break;
-    }
+        sink.send(h, payload.data());
+    } while (got == payload.size());
     sink.flush_to_disk();
     return 0;
 }
