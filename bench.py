@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+USE_DIST = False       # set in main(): a torch.distributed process group is up
 
 WORKLOADS = {
     # name: (description, complex?, taps builder, log2 samples per GPU, channels)
@@ -170,7 +171,30 @@ def cpu_baseline(taps, cplx, log2n):
             "sample": what + " (oracle/sdr_oracle.c fp32 port; oracle/_ref not present)"}
 
 
+_REAL_STDOUT = None
+
+
+def keep_stdout_for_the_json_line():
+    """Libraries write to stdout behind Python's back (RCCL prints a five-line version banner
+    on rank 0 when its communicator comes up).  The contract is ONE JSON line on stdout: fd 1
+    is pointed at stderr for the run, and the JSON line goes to the saved descriptor."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_json_line(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
+    keep_stdout_for_the_json_line()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -200,8 +224,15 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    global USE_DIST
+    # SDR_BENCH_FORCE_DIST=1: go through the process group even with one rank (rehearses the
+    # RCCL calls of the multi-GPU run on a one-GPU box)
+    USE_DIST = world > 1 or bool(os.environ.get("SDR_BENCH_FORCE_DIST"))
+    if USE_DIST:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -251,7 +282,7 @@ def run_and_report(args, torch, dist, rank, world, dev, step, units, step_bytes,
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
         torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -262,7 +293,7 @@ def run_and_report(args, torch, dist, rank, world, dev, step, units, step_bytes,
         ev[i + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if USE_DIST:
         dist.barrier()
         torch.cuda.synchronize()
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -302,8 +333,8 @@ def run_and_report(args, torch, dist, rank, world, dev, step, units, step_bytes,
             out["cpu_baseline"] = cpu_baseline(taps, cplx, min(args.cpu_log2n, log2n))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit_json_line(out)
+    if USE_DIST:
         dist.destroy_process_group()
 
 
