@@ -2,10 +2,10 @@
 //
 // Same contract as fir_direct (y[i] = sum_j h[j] x[i-j] over the virtual stream
 // history|input), but the arithmetic is a fast convolution: the direct form costs
-// ntaps packed FMAs per complex sample and is VALU-bound from ~80 taps up
-// (DESIGN.md 4.1); this kernel costs ~50 packed ops per sample whatever the tap
-// count (up to 4096-64 taps), which puts medium and long filters back under the
-// HBM roofline.
+// ntaps packed FMAs per complex sample and is VALU-bound from ~35 dense taps up
+// (DESIGN.md 4.1, 4.2); this kernel costs ~45 packed ops per sample whatever the tap
+// count (one transform pair up to 2049 taps, partitioned beyond, up to 131072),
+// which puts medium and long filters back under the HBM roofline.
 //
 // One workgroup (256 lanes) owns tiles of N = 4096 input samples: halo (>= ntaps-1,
 // multiple of 64) old samples + L = N - halo new ones; it produces L outputs per tile
@@ -23,8 +23,10 @@
 //   per kernel), then the mirrored inverse (C', exchange 2', B', exchange 1', A') with
 //   conjugated twiddles, and lane r stores y[256 n2 + r] for the L new positions.
 //
-// The three twiddle sets are per-lane constants kept in registers for the life of the
-// (persistent) workgroup.  Real signals ride two-at-a-time as re/im of one complex
+// The W_4096 twiddles and the filter spectrum are per-lane constants kept in registers for
+// the life of the (persistent) workgroup, the W_256 twiddles sit in a 256-entry LDS table;
+// all come from tables computed on the host in double (no sincos on the device).  The next
+// tile's loads are issued in shares between the phases of the current tile (SDR_SPREAD).  Real signals ride two-at-a-time as re/im of one complex
 // FFT (the filter is real-tap, hence linear over that pairing), like in fir_direct.
 //
 // fp32 error: ~3e-7 of the tile's RMS (measured against a float64 convolution), inside
@@ -42,6 +44,7 @@
 #ifndef SDR_ST_NT
 #define SDR_ST_NT 1
 #endif
+// shares the next tile's 16 row loads are issued in: 0 = one burst, 1 = three, 2 = six, 3 = eight
 #ifndef SDR_SPREAD
 #define SDR_SPREAD 2
 #endif
