@@ -73,17 +73,42 @@ int main(int argc, char** argv) {
         if (kind == "hilbert") {
             taps = sdr::hilbert<float>(n);
         } else {
-            auto wexpr = kfr::window_blackman<float>(n);
-            kfr::expression_pointer<float> w = kfr::to_pointer(wexpr);
             float f1 = argc > 4 ? strtof(argv[4], nullptr) : 0.f;
             float f2 = argc > 5 ? strtof(argv[5], nullptr) : 0.f;
-            if (kind == "lowpass") kfr::fir_lowpass(taps, f1, w, true);
-            else if (kind == "highpass") kfr::fir_highpass(taps, f1, w, true);
-            else if (kind == "bandpass") kfr::fir_bandpass(taps, f1, f2, w, true);
-            else if (kind == "bandstop") kfr::fir_bandstop(taps, f1, f2, w, true);
-            else return 1;
+            std::string wname = argc > 6 ? argv[6] : "blackman";
+            // (each window expression is bound to a named variable before to_pointer: see the
+            // note on g++ at the top of this file)
+            auto design = [&](auto wexpr) {
+                kfr::expression_pointer<float> w = kfr::to_pointer(wexpr);
+                if (kind == "lowpass") kfr::fir_lowpass(taps, f1, w, true);
+                else if (kind == "highpass") kfr::fir_highpass(taps, f1, w, true);
+                else if (kind == "bandpass") kfr::fir_bandpass(taps, f1, f2, w, true);
+                else if (kind == "bandstop") kfr::fir_bandstop(taps, f1, f2, w, true);
+                else return 1;
+                return 0;
+            };
+            int rc = 1;
+            if (wname == "blackman") rc = design(kfr::window_blackman<float>(n));
+            else if (wname == "rectangular") rc = design(kfr::internal::expression_rectangular<float>(n));
+            else if (wname == "hann") rc = design(kfr::window_hann<float>(n));
+            else if (wname == "hamming") rc = design(kfr::window_hamming<float>(n));
+            else if (wname == "blackman_harris") rc = design(kfr::window_blackman_harris<float>(n));
+            if (rc) return rc;
         }
         write_all(taps.data(), n * sizeof(float));
+        return 0;
+    }
+    if (cmd == "window" && argc >= 4) { // window NAME N: the window itself
+        std::string wname = argv[2];
+        size_t n = strtoull(argv[3], nullptr, 10);
+        kfr::univector<float> w(n);
+        if (wname == "blackman") w = kfr::window_blackman<float>(n);
+        else if (wname == "rectangular") w = kfr::internal::expression_rectangular<float>(n);
+        else if (wname == "hann") w = kfr::window_hann<float>(n);
+        else if (wname == "hamming") w = kfr::window_hamming<float>(n);
+        else if (wname == "blackman_harris") w = kfr::window_blackman_harris<float>(n);
+        else return 1;
+        write_all(w.data(), n * sizeof(float));
         return 0;
     }
     if (cmd == "fir" && argc >= 5) {

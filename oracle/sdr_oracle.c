@@ -40,6 +40,27 @@ void sdro_window_blackman(float* w, size_t n) {
     }
 }
 
+/* The other windows the FIR designs can take (libs/kfr/dsp/window.hpp:120-139 rectangular,
+ * :204-223 hann, :247-267 hamming alpha 0.54, :314-334 blackman_harris), all over the same
+ * symmetric linspace 0..1 as the Blackman window above.  window: 0 blackman, 1 rectangular,
+ * 2 hann, 3 hamming, 4 blackman_harris. */
+int sdro_window(int window, float* w, size_t n) {
+    if (window == 0) { sdro_window_blackman(w, n); return 0; }
+    if (window < 0 || window > 4) return -1;
+    const float offset = (1.0f - 0.0f) / (float)(n - 1);
+    for (size_t i = 0; i < n; ++i) {
+        const float t = 0.0f + (float)(int64_t)i * offset;
+        const float x = TWO_PI_F * t;
+        switch (window) {
+            case 1: w[i] = 1.0f; break;
+            case 2: w[i] = 0.5f * (1.0f - cosf(x)); break;
+            case 3: w[i] = 0.54f - (1.0f - 0.54f) * cosf(x); break;
+            default: w[i] = 0.35875f - 0.48829f * cosf(x) + 0.14128f * cosf(2.0f * x) - 0.01168f * cosf(3.0f * x); break;
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ A1 ---
  * include/sdr/hilbert.hpp:33-63. */
 void sdro_hilbert_taps(float* taps, size_t n) {
@@ -87,8 +108,12 @@ static float symmlin(float symsize, size_t n, size_t i) {
 /* ------------------------------------------------------------------ A7 ---
  * libs/kfr/dsp/fir_design.hpp:35-116, Blackman window, normalize=true. */
 void sdro_fir_design(int kind, float* taps, size_t n, float f1, float f2) {
+    (void)sdro_fir_design_window(kind, 0, taps, n, f1, f2);
+}
+
+int sdro_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2) {
     float* wnd = (float*)malloc(sizeof(float) * (n ? n : 1));
-    sdro_window_blackman(wnd, n);
+    if (sdro_window(window, wnd, n) != 0) { free(wnd); return -1; }
     float sum = 0.0f;
     if (kind == 0 || kind == 1) {
         /* :38-44 / :55-61 */
@@ -116,6 +141,7 @@ void sdro_fir_design(int kind, float* taps, size_t n, float f1, float f2) {
     const float invsum = (kind == 0 || kind == 3) ? 1.0f / sum : 1.0f / (sum + 1);
     for (size_t i = 0; i < n; ++i) taps[i] = taps[i] * invsum;
     free(wnd);
+    return 0;
 }
 
 /* --------------------------------------------------------------- A3/A4 ---

@@ -35,6 +35,10 @@ void sdro_hilbert_taps(float* taps, size_t n);
  * normalize=true (libs/kfr/dsp/fir_design.hpp:35-116).
  * kind: 0 lowpass(f1) 1 highpass(f1) 2 bandpass(f1,f2) 3 bandstop(f1,f2). */
 void sdro_fir_design(int kind, float* taps, size_t n, float f1, float f2);
+/* The same designs under another window (libs/kfr/dsp/window.hpp): 0 blackman, 1 rectangular,
+ * 2 hann, 3 hamming (alpha 0.54), 4 blackman_harris.  -1 for an unknown window. */
+int sdro_window(int window, float* w, size_t n);
+int sdro_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2);
 
 /* ---- streaming FIR (kfr::fir_state + kfr::fir, libs/kfr/dsp/fir.hpp:57-68,
  *      119-148): y[n] = sum_j h[j] x[n-j], zero initial history, history

@@ -59,8 +59,20 @@ designs = [("lowpass", 127, 0.1, 0.0), ("lowpass", 128, 0.25, 0.0), ("highpass",
 for kind, n, f1, f2 in designs:
     out, _, _ = run(["ref_harness", "taps", kind, str(n), repr(f1), repr(f2)])
     taps["%s_%d_%g_%g" % (kind, n, f1, f2)] = np.frombuffer(out, np.float32)
+# the same designs under the other windows, and the windows themselves
+for wname in ("rectangular", "hann", "hamming", "blackman_harris", "blackman"):
+    for n in (9, 64, 127, 1000):
+        out, _, _ = run(["ref_harness", "window", wname, str(n)])
+        taps["window_%s_%d" % (wname, n)] = np.frombuffer(out, np.float32)
+    if wname == "blackman":
+        continue
+    for kind, n, f1, f2 in (("lowpass", 127, 0.1, 0.0), ("highpass", 63, 0.2, 0.0), ("bandpass", 255, 0.05, 0.15),
+                            ("bandstop", 65, 0.1, 0.3)):
+        out, _, _ = run(["ref_harness", "taps", kind, str(n), repr(f1), repr(f2), wname])
+        taps["%s_%d_%g_%g_%s" % (kind, n, f1, f2, wname)] = np.frombuffer(out, np.float32)
 save("taps.npz", **taps)
-manifest["taps.npz"] = "ref_harness taps hilbert N ; ref_harness taps KIND N F1 F2 (key = KIND_N_F1_F2)"
+manifest["taps.npz"] = ("ref_harness taps hilbert N ; ref_harness taps KIND N F1 F2 [WINDOW] (key = KIND_N_F1_F2[_WINDOW]) ; "
+                        "ref_harness window NAME N (key = window_NAME_N)")
 
 # ---- (ii) gen ----------------------------------------------------------------
 gens = {

@@ -35,6 +35,10 @@ def lib():
         L.sdro_window_blackman.argtypes = [fp, C.c_size_t]
         L.sdro_hilbert_taps.argtypes = [fp, C.c_size_t]
         L.sdro_fir_design.argtypes = [C.c_int, fp, C.c_size_t, C.c_float, C.c_float]
+        L.sdro_window.argtypes = [C.c_int, fp, C.c_size_t]
+        L.sdro_window.restype = C.c_int
+        L.sdro_fir_design_window.argtypes = [C.c_int, C.c_int, fp, C.c_size_t, C.c_float, C.c_float]
+        L.sdro_fir_design_window.restype = C.c_int
         L.sdro_fir_create.argtypes = [fp, C.c_size_t, C.c_int, C.c_int]
         L.sdro_fir_create.restype = C.c_void_p
         L.sdro_fir_reset.argtypes = [C.c_void_p]
@@ -79,10 +83,19 @@ def hilbert_taps(n):
 FIR_KINDS = {"lowpass": 0, "highpass": 1, "bandpass": 2, "bandstop": 3}
 
 
-def fir_design(kind, n, f1, f2=0.0):
+WINDOWS = {"blackman": 0, "rectangular": 1, "hann": 2, "hamming": 3, "blackman_harris": 4}
+
+
+def fir_design(kind, n, f1, f2=0.0, window="blackman"):
     t = np.empty(n, np.float32)
-    lib().sdro_fir_design(FIR_KINDS[kind], _fp(t), n, f1, f2)
+    assert lib().sdro_fir_design_window(FIR_KINDS[kind], WINDOWS[window], _fp(t), n, f1, f2) == 0
     return t
+
+
+def window(name, n):
+    w = np.empty(n, np.float32)
+    assert lib().sdro_window(WINDOWS[name], _fp(w), n) == 0
+    return w
 
 
 class Fir:
