@@ -10,8 +10,9 @@
 // kfr::fir + kfr::fir_lowpass/... , libs/kfr/dsp/fir.hpp, fir_design.hpp): the keyword
 // options
 //   fir=(lowpass|highpass|bandpass|bandstop) [taps=COUNT] cutoff=F [cutoff2=F]
+//   [window=(blackman|rectangular|hann|hamming|blackman_harris)]
 // run every forwarded Signal / ComplexSignal packet through that FIR on the GPU
-// (taps designed like kfr::fir_* with a Blackman window, F = Hz / sample_rate; one
+// (taps designed like kfr::fir_* under that kfr window, Blackman by default, F = Hz / sample_rate; one
 // filter state shared by the forwarded sample packets, no group-delay skip).
 #include <cstdlib>
 #include <iostream>
@@ -32,6 +33,9 @@ const cli::Choices kContents = {
     {"complex_spectrum", host::kComplexSpectrum}};
 const cli::Choices kFirKinds = {{"none", -1}, {"lowpass", SDR_LOWPASS}, {"highpass", SDR_HIGHPASS},
                                 {"bandpass", SDR_BANDPASS}, {"bandstop", SDR_BANDSTOP}};
+const cli::Choices kWindows = {{"blackman", SDR_WINDOW_BLACKMAN}, {"rectangular", SDR_WINDOW_RECTANGULAR},
+                               {"hann", SDR_WINDOW_HANN}, {"hamming", SDR_WINDOW_HAMMING},
+                               {"blackman_harris", SDR_WINDOW_BLACKMAN_HARRIS}};
 
 struct Rule {
     bool drop_mode;
@@ -65,16 +69,17 @@ int main(int argc, char* argv[]) {
     cli::Option taps = cli::Option::uint("taps", "COUNT", 127);
     cli::Option cutoff = cli::Option::real("cutoff", "F", 0.0f);
     cli::Option cutoff2 = cli::Option::real("cutoff2", "F", 0.0f);
+    cli::Option window = cli::Option::choice("window", kWindows, SDR_WINDOW_BLACKMAN);
 
     const std::vector<cli::Option*> positional = {&mode, &ids, &content};
     for (int i = 1; i < argc; ++i)
         if (std::string(argv[i]) == "help") {
             cli::usage(argv[0], positional, {}, std::cerr);
             std::cerr << "Extension (GPU FIR on forwarded sample packets): [fir=(lowpass|highpass|bandpass|bandstop)]"
-                         " [taps=COUNT] [cutoff=F] [cutoff2=F]" << std::endl;
+                         " [taps=COUNT] [cutoff=F] [cutoff2=F] [window=(blackman|rectangular|hann|hamming|blackman_harris)]" << std::endl;
             return -1;
         }
-    if (!cli::parse(positional, {&fir, &taps, &cutoff, &cutoff2}, argc, argv, std::cerr)) return -1;
+    if (!cli::parse(positional, {&fir, &taps, &cutoff, &cutoff2, &window}, argc, argv, std::cerr)) return -1;
 
     if (!mode.is_set()) {
         std::cerr << "error: stream_filter: option 'mode' is required" << std::endl;
@@ -107,7 +112,8 @@ int main(int argc, char* argv[]) {
     }
     host::PipelineConfig cfg;
     cfg.taps.resize(ntaps);
-    if (sdr_fir_design(fir.as_choice(), cfg.taps.data(), ntaps, cutoff.as_float(), cutoff2.as_float()) != SDR_OK) {
+    if (sdr_fir_design_window(fir.as_choice(), window.as_choice(), cfg.taps.data(), ntaps, cutoff.as_float(),
+                              cutoff2.as_float()) != SDR_OK) {
         std::cerr << "error: stream_filter: " << sdr_last_error() << std::endl;
         return -1;
     }

@@ -52,6 +52,17 @@ int sdr_hilbert_taps(float* taps, size_t n);
  * (reference libs/kfr/dsp/fir_design.hpp:35-116, window.hpp:290-311).
  * Frequencies are normalised (Hz / sample_rate); f2 only for band kinds. */
 int sdr_fir_design(int kind, float* taps, size_t n, float f1, float f2);
+/* The same designs under another of kfr's windows (reference libs/kfr/dsp/window.hpp:
+ * :120-139 rectangular, :204-223 hann, :247-267 hamming alpha 0.54, :290-311 blackman
+ * alpha 0.16, :314-334 blackman_harris; all symmetric). */
+enum {
+    SDR_WINDOW_BLACKMAN = 0,
+    SDR_WINDOW_RECTANGULAR = 1,
+    SDR_WINDOW_HANN = 2,
+    SDR_WINDOW_HAMMING = 3,
+    SDR_WINDOW_BLACKMAN_HARRIS = 4
+};
+int sdr_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2);
 
 /* Longest filter: 64 partitions of 2048 taps in the partitioned fast convolution. */
 #define SDR_MAX_TAPS 131072

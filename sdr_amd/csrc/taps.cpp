@@ -39,6 +39,30 @@ std::vector<float> blackman(size_t n) {
     return w;
 }
 
+// The other windows a design can take, over the same grid t_i = i/(n-1)
+// (libs/kfr/dsp/window.hpp:120-139 rectangular, :204-223 hann, :247-267 hamming with
+// alpha 0.54, :314-334 blackman_harris).
+bool design_window(int window, size_t n, std::vector<float>& w) {
+    if (window == SDR_WINDOW_BLACKMAN) {
+        w = blackman(n);
+        return true;
+    }
+    if (window < SDR_WINDOW_BLACKMAN || window > SDR_WINDOW_BLACKMAN_HARRIS) return false;
+    w.resize(n);
+    const float step = 1.0f / static_cast<float>(n - 1);
+    for (size_t i = 0; i < n; ++i) {
+        const float x = 2.0f * kPi * (static_cast<float>(static_cast<int64_t>(i)) * step);
+        switch (window) {
+            case SDR_WINDOW_RECTANGULAR: w[i] = 1.0f; break;
+            case SDR_WINDOW_HANN: w[i] = 0.5f * (1.0f - std::cos(x)); break;
+            case SDR_WINDOW_HAMMING: w[i] = 0.54f - (1.0f - 0.54f) * std::cos(x); break;
+            default:
+                w[i] = 0.35875f - 0.48829f * std::cos(x) + 0.14128f * std::cos(2.0f * x) - 0.01168f * std::cos(3.0f * x);
+        }
+    }
+    return true;
+}
+
 // kfr::sinc (libs/kfr/base/sin_cos.hpp:228-232)
 inline float sinc(float x) {
     return std::fabs(x) <= 1.1920928955078125e-07f ? 1.0f : std::sin(x) / x;
@@ -80,9 +104,14 @@ extern "C" int sdr_hilbert_taps(float* taps, size_t n) {
 }
 
 extern "C" int sdr_fir_design(int kind, float* taps, size_t n, float f1, float f2) {
+    return sdr_fir_design_window(kind, SDR_WINDOW_BLACKMAN, taps, n, f1, f2);
+}
+
+extern "C" int sdr_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2) {
     if (!taps || n < 2) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: need taps and n >= 2");
     if (kind < SDR_LOWPASS || kind > SDR_BANDSTOP) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: unknown kind");
-    const std::vector<float> w = blackman(n);
+    std::vector<float> w;
+    if (!design_window(window, n, w)) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: unknown window");
     const bool odd = n & 1;
     if (kind == SDR_LOWPASS || kind == SDR_HIGHPASS) {
         // fir_design.hpp:38-44 and :55-61
