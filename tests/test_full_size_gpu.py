@@ -150,3 +150,34 @@ def test_config5_full_size_chunk():
         ref, first = staged_window(stages, xw)
         got = out[s:s + len(ref)].cpu().numpy()
         assert max_err(got[first:first + W], ref[first:first + W]) <= TOL * rms, wb
+
+
+@pytest.mark.parametrize("ntaps,cplx,log2n", [(127, False, 32), (15, False, 32), (127, True, 31), (4095, False, 32)])
+def test_calls_beyond_2_to_the_32_samples(ntaps, cplx, log2n):
+    """One call on more than 2^32 real (2^31 complex) samples -- the whole of BASELINE config 5's
+    buffer on one GPU: sample indices are 64-bit end to end.  Windows around 2^31, 2^32 and the
+    end of the buffer against the oracle; nothing written past the end."""
+    import torch
+    n = (1 << log2n) + 12345
+    w = 2 if cplx else 1
+    taps = sdr_amd.fir_lowpass(ntaps, 0.1) if ntaps < 1000 else sdr_amd.fir_bandpass(ntaps, 0.1, 0.2)
+    st = sdr_amd.FirState(taps, cplx)
+    x = torch.empty(n * w, dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(ntaps)
+    x.uniform_(-1, 1, generator=g)
+    y = torch.full((n * w + 64,), 777.0, dtype=torch.float32, device="cuda")
+    st.process_device(x.data_ptr(), n, y.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool((y[n * w:] == 777.0).all())
+    rms = float(y[w * (1 << 20): w * ((1 << 20) + (1 << 22))].to(torch.float64).pow(2).mean().sqrt()) * np.sqrt(w)
+    W = 2048
+    for s in [0, (1 << 31) // w - 1000, (1 << 31) - 1000, (1 << 32) // w - 1000, n - W]:
+        if s + W > n:
+            continue
+        lo = max(0, s - (ntaps - 1))
+        xin = x[lo * w:(s + W) * w].cpu().numpy()
+        xin = xin.view(np.complex64) if cplx else xin
+        ref = O.fir(taps, xin)[s - lo:]
+        got = y[s * w:(s + W) * w].cpu().numpy()
+        got = got.view(np.complex64) if cplx else got
+        assert max_err(got, ref) <= TOL * rms, (ntaps, cplx, s)
