@@ -181,3 +181,44 @@ def test_calls_beyond_2_to_the_32_samples(ntaps, cplx, log2n):
         got = y[s * w:(s + W) * w].cpu().numpy()
         got = got.view(np.complex64) if cplx else got
         assert max_err(got, ref) <= TOL * rms, (ntaps, cplx, s)
+
+
+def test_config5_whole_buffer_in_one_call():
+    """BASELINE config 5's whole 2^32-sample buffer generated and filtered by ONE call on one GPU
+    (2 101 300 packets of 2044 samples, 17 GB of outputs): the tail of the buffer, past 2^32,
+    equals what a second generator + chain positioned there (Gen.advance, Chain.seek, primed with
+    the halo packets) produce -- packet and sample indices are 64-bit inside the fused kernel."""
+    import torch
+    from sdr_amd import sharding
+    B = 2044
+    blocks = 2101300                          # x 2044 = 4 295 057 200 > 2^32
+    cps = float(np.float32(100e3) / np.float32(1e6))
+    stages = STAGES()
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = sdr_amd.Gen("sine", False, 1.0, cps, 0.0, B)
+    chain = sdr_amd.Chain(stages, False)
+    out = torch.empty(blocks * B, dtype=torch.float32, device="cuda")
+    done = chain.generate_device(gen, blocks, out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert done == blocks * B - 63 and done > (1 << 32)
+    # the start of the stream against the oracle
+    x, _ = O.gen_real(8, B, 1.0, cps, 0.0, sdr_amd.WAVEFORMS["sine"])
+    ref = O.fir(stages[1][0], O.fir(stages[0][0], x)[63:])
+    assert max_err(out[:len(ref)].cpu().numpy(), ref) <= TOL * np.sqrt(np.mean(ref[1000:].astype(np.float64) ** 2))
+    # the last 900 packets, produced independently from their own position
+    tail_blocks = 900
+    first = blocks - tail_blocks
+    halo = sharding.plan_generated_chain(blocks, 2, B, 253)[1][2]
+    gen2 = sdr_amd.Gen("sine", False, 1.0, cps, 0.0, B)
+    chain2 = sdr_amd.Chain(stages, False)
+    gen2.advance(first - halo)
+    chain2.seek((first - halo) * B)
+    tmp = torch.empty((tail_blocks + halo) * B, dtype=torch.float32, device="cuda")
+    assert chain2.generate_device(gen2, halo, tmp.data_ptr(), stream=stream) == halo * B      # priming, discarded
+    n2 = chain2.generate_device(gen2, tail_blocks, tmp.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert n2 == tail_blocks * B
+    a = out[done - n2:done]
+    b = tmp[:n2]
+    rms = float(a.to(torch.float64).pow(2).mean().sqrt())
+    assert float((a - b).abs().max()) <= 3e-6 * rms      # two fp32 results with different tile offsets
