@@ -10,7 +10,7 @@
 // kfr::fir + kfr::fir_lowpass/... , libs/kfr/dsp/fir.hpp, fir_design.hpp): the keyword
 // options
 //   fir=(lowpass|highpass|bandpass|bandstop) [taps=COUNT] cutoff=F [cutoff2=F]
-//   [window=(blackman|rectangular|hann|hamming|blackman_harris)]
+//   [window=(blackman|rectangular|hann|hamming|blackman_harris|kaiser)] [beta=B]
 // run every forwarded Signal / ComplexSignal packet through that FIR on the GPU
 // (taps designed like kfr::fir_* under that kfr window, Blackman by default, F = Hz / sample_rate; one
 // filter state shared by the forwarded sample packets, no group-delay skip).
@@ -35,7 +35,7 @@ const cli::Choices kFirKinds = {{"none", -1}, {"lowpass", SDR_LOWPASS}, {"highpa
                                 {"bandpass", SDR_BANDPASS}, {"bandstop", SDR_BANDSTOP}};
 const cli::Choices kWindows = {{"blackman", SDR_WINDOW_BLACKMAN}, {"rectangular", SDR_WINDOW_RECTANGULAR},
                                {"hann", SDR_WINDOW_HANN}, {"hamming", SDR_WINDOW_HAMMING},
-                               {"blackman_harris", SDR_WINDOW_BLACKMAN_HARRIS}};
+                               {"blackman_harris", SDR_WINDOW_BLACKMAN_HARRIS}, {"kaiser", SDR_WINDOW_KAISER}};
 
 struct Rule {
     bool drop_mode;
@@ -70,16 +70,17 @@ int main(int argc, char* argv[]) {
     cli::Option cutoff = cli::Option::real("cutoff", "F", 0.0f);
     cli::Option cutoff2 = cli::Option::real("cutoff2", "F", 0.0f);
     cli::Option window = cli::Option::choice("window", kWindows, SDR_WINDOW_BLACKMAN);
+    cli::Option beta = cli::Option::real("beta", "B", 0.5f); // the Kaiser window's parameter (kfr's default)
 
     const std::vector<cli::Option*> positional = {&mode, &ids, &content};
     for (int i = 1; i < argc; ++i)
         if (std::string(argv[i]) == "help") {
             cli::usage(argv[0], positional, {}, std::cerr);
             std::cerr << "Extension (GPU FIR on forwarded sample packets): [fir=(lowpass|highpass|bandpass|bandstop)]"
-                         " [taps=COUNT] [cutoff=F] [cutoff2=F] [window=(blackman|rectangular|hann|hamming|blackman_harris)]" << std::endl;
+                         " [taps=COUNT] [cutoff=F] [cutoff2=F] [window=(blackman|rectangular|hann|hamming|blackman_harris|kaiser)] [beta=B]" << std::endl;
             return -1;
         }
-    if (!cli::parse(positional, {&fir, &taps, &cutoff, &cutoff2, &window}, argc, argv, std::cerr)) return -1;
+    if (!cli::parse(positional, {&fir, &taps, &cutoff, &cutoff2, &window, &beta}, argc, argv, std::cerr)) return -1;
 
     if (!mode.is_set()) {
         std::cerr << "error: stream_filter: option 'mode' is required" << std::endl;
@@ -112,8 +113,8 @@ int main(int argc, char* argv[]) {
     }
     host::PipelineConfig cfg;
     cfg.taps.resize(ntaps);
-    if (sdr_fir_design_window(fir.as_choice(), window.as_choice(), cfg.taps.data(), ntaps, cutoff.as_float(),
-                              cutoff2.as_float()) != SDR_OK) {
+    if (sdr_fir_design_window(fir.as_choice(), window.as_choice(), beta.as_float(), cfg.taps.data(), ntaps,
+                              cutoff.as_float(), cutoff2.as_float()) != SDR_OK) {
         std::cerr << "error: stream_filter: " << sdr_last_error() << std::endl;
         return -1;
     }

@@ -54,15 +54,18 @@ int sdr_hilbert_taps(float* taps, size_t n);
 int sdr_fir_design(int kind, float* taps, size_t n, float f1, float f2);
 /* The same designs under another of kfr's windows (reference libs/kfr/dsp/window.hpp:
  * :120-139 rectangular, :204-223 hann, :247-267 hamming alpha 0.54, :290-311 blackman
- * alpha 0.16, :314-334 blackman_harris; all symmetric). */
+ * alpha 0.16, :314-334 blackman_harris, :336-358 kaiser with window_param = beta over
+ * kfr::modzerobessel, libs/kfr/base/modzerobessel.hpp:42-94; all symmetric).  window_param
+ * is read by the Kaiser window only. */
 enum {
     SDR_WINDOW_BLACKMAN = 0,
     SDR_WINDOW_RECTANGULAR = 1,
     SDR_WINDOW_HANN = 2,
     SDR_WINDOW_HAMMING = 3,
-    SDR_WINDOW_BLACKMAN_HARRIS = 4
+    SDR_WINDOW_BLACKMAN_HARRIS = 4,
+    SDR_WINDOW_KAISER = 5
 };
-int sdr_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2);
+int sdr_fir_design_window(int kind, int window, float window_param, float* taps, size_t n, float f1, float f2);
 
 /* Longest filter: 64 partitions of 2048 taps in the partitioned fast convolution. */
 #define SDR_MAX_TAPS 131072

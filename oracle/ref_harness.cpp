@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
             float f1 = argc > 4 ? strtof(argv[4], nullptr) : 0.f;
             float f2 = argc > 5 ? strtof(argv[5], nullptr) : 0.f;
             std::string wname = argc > 6 ? argv[6] : "blackman";
+            float wparam = argc > 7 ? strtof(argv[7], nullptr) : 0.5f;
             // (each window expression is bound to a named variable before to_pointer: see the
             // note on g++ at the top of this file)
             auto design = [&](auto wexpr) {
@@ -93,20 +94,23 @@ int main(int argc, char** argv) {
             else if (wname == "hann") rc = design(kfr::window_hann<float>(n));
             else if (wname == "hamming") rc = design(kfr::window_hamming<float>(n));
             else if (wname == "blackman_harris") rc = design(kfr::window_blackman_harris<float>(n));
+            else if (wname == "kaiser") rc = design(kfr::window_kaiser<float>(n, wparam));
             if (rc) return rc;
         }
         write_all(taps.data(), n * sizeof(float));
         return 0;
     }
-    if (cmd == "window" && argc >= 4) { // window NAME N: the window itself
+    if (cmd == "window" && argc >= 4) { // window NAME N [PARAM]: the window itself
         std::string wname = argv[2];
         size_t n = strtoull(argv[3], nullptr, 10);
+        float wparam = argc > 4 ? strtof(argv[4], nullptr) : 0.5f;
         kfr::univector<float> w(n);
         if (wname == "blackman") w = kfr::window_blackman<float>(n);
         else if (wname == "rectangular") w = kfr::internal::expression_rectangular<float>(n);
         else if (wname == "hann") w = kfr::window_hann<float>(n);
         else if (wname == "hamming") w = kfr::window_hamming<float>(n);
         else if (wname == "blackman_harris") w = kfr::window_blackman_harris<float>(n);
+        else if (wname == "kaiser") w = kfr::window_kaiser<float>(n, wparam);
         else return 1;
         write_all(w.data(), n * sizeof(float));
         return 0;

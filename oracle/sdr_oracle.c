@@ -43,10 +43,42 @@ void sdro_window_blackman(float* w, size_t n) {
 /* The other windows the FIR designs can take (libs/kfr/dsp/window.hpp:120-139 rectangular,
  * :204-223 hann, :247-267 hamming alpha 0.54, :314-334 blackman_harris), all over the same
  * symmetric linspace 0..1 as the Blackman window above.  window: 0 blackman, 1 rectangular,
- * 2 hann, 3 hamming, 4 blackman_harris. */
-int sdro_window(int window, float* w, size_t n) {
+ * 2 hann, 3 hamming, 4 blackman_harris, 5 kaiser (param = beta). */
+/* kfr::modzerobessel in fp32 (libs/kfr/base/modzerobessel.hpp:42-94): the power series of
+ * I0, sum_k ((x/2)^2)^k / (k!)^2, accumulated term by term -- 1 + q, then 20 more terms with
+ * coefficients 1/((k+2)!)^2 (rounded to fp32 from their exact values). */
+static float modzerobessel_f(float x) {
+    const float h = x * 0.5f;
+    const float q = h * h;
+    float num = q;
+    float result = 1.0f + q;
+    double fact = 1.0; /* (k+1)! */
+    for (int k = 0; k < 20; ++k) {
+        fact *= (double)(k + 2);
+        const float coef = (float)(1.0 / (fact * fact));
+        num *= q;
+        result = num * coef + result;
+    }
+    return result;
+}
+
+/* kfr::window_kaiser (libs/kfr/dsp/window.hpp:336-358): I0(beta sqrt(1 - t^2)) / I0(beta) on
+ * the plain linspace t_i = -1 + i * (2 / (n - 1)). */
+void sdro_window_kaiser(float* w, size_t n, float beta) {
+    const float m = 1.0f / modzerobessel_f(beta);
+    const float offset = (1.0f - -1.0f) / (float)(n - 1);
+    for (size_t i = 0; i < n; ++i) {
+        const float t = -1.0f + (float)(int64_t)i * offset;
+        w[i] = modzerobessel_f(beta * sqrtf(1.0f - t * t)) * m;
+    }
+}
+
+int sdro_window(int window, float* w, size_t n) { return sdro_window_param(window, 0.5f, w, n); }
+
+int sdro_window_param(int window, float param, float* w, size_t n) {
     if (window == 0) { sdro_window_blackman(w, n); return 0; }
-    if (window < 0 || window > 4) return -1;
+    if (window == 5) { sdro_window_kaiser(w, n, param); return 0; }
+    if (window < 0 || window > 5) return -1;
     const float offset = (1.0f - 0.0f) / (float)(n - 1);
     for (size_t i = 0; i < n; ++i) {
         const float t = 0.0f + (float)(int64_t)i * offset;
@@ -112,8 +144,12 @@ void sdro_fir_design(int kind, float* taps, size_t n, float f1, float f2) {
 }
 
 int sdro_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2) {
+    return sdro_fir_design_window_param(kind, window, 0.5f, taps, n, f1, f2);
+}
+
+int sdro_fir_design_window_param(int kind, int window, float param, float* taps, size_t n, float f1, float f2) {
     float* wnd = (float*)malloc(sizeof(float) * (n ? n : 1));
-    if (sdro_window(window, wnd, n) != 0) { free(wnd); return -1; }
+    if (sdro_window_param(window, param, wnd, n) != 0) { free(wnd); return -1; }
     float sum = 0.0f;
     if (kind == 0 || kind == 1) {
         /* :38-44 / :55-61 */

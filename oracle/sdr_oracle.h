@@ -39,6 +39,10 @@ void sdro_fir_design(int kind, float* taps, size_t n, float f1, float f2);
  * 2 hann, 3 hamming (alpha 0.54), 4 blackman_harris.  -1 for an unknown window. */
 int sdro_window(int window, float* w, size_t n);
 int sdro_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2);
+/* ... and 5 = kaiser (window.hpp:336-358, modzerobessel.hpp:42-94), param = beta (kfr's default 0.5). */
+void sdro_window_kaiser(float* w, size_t n, float beta);
+int sdro_window_param(int window, float param, float* w, size_t n);
+int sdro_fir_design_window_param(int kind, int window, float param, float* taps, size_t n, float f1, float f2);
 
 /* ---- streaming FIR (kfr::fir_state + kfr::fir, libs/kfr/dsp/fir.hpp:57-68,
  *      119-148): y[n] = sum_j h[j] x[n-j], zero initial history, history

@@ -37,7 +37,7 @@ def lib():
         L.sdr_device_count.restype = C.c_int
         L.sdr_hilbert_taps.argtypes = [fp, sz]
         L.sdr_fir_design.argtypes = [C.c_int, fp, sz, C.c_float, C.c_float]
-        L.sdr_fir_design_window.argtypes = [C.c_int, C.c_int, fp, sz, C.c_float, C.c_float]
+        L.sdr_fir_design_window.argtypes = [C.c_int, C.c_int, C.c_float, fp, sz, C.c_float, C.c_float]
         L.sdr_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int]
         L.sdr_fir_process_device.argtypes = [vp, vp, sz, sz, vp, sz, vp]
         L.sdr_fir_process.argtypes = [vp, vp, sz, vp]
@@ -102,29 +102,30 @@ def hilbert(n):
     return t
 
 
-WINDOWS_FIR = {"blackman": 0, "rectangular": 1, "hann": 2, "hamming": 3, "blackman_harris": 4}
+WINDOWS_FIR = {"blackman": 0, "rectangular": 1, "hann": 2, "hamming": 3, "blackman_harris": 4, "kaiser": 5}
 
 
-def fir_design(kind, n, f1, f2=0.0, window="blackman"):
+def fir_design(kind, n, f1, f2=0.0, window="blackman", beta=0.5):
+    """kfr::fir_* style taps; `beta` is the Kaiser window's parameter."""
     t = np.empty(int(n), np.float32)
-    _check(lib().sdr_fir_design_window(_KINDS[kind], WINDOWS_FIR[window], _fp(t), int(n), f1, f2))
+    _check(lib().sdr_fir_design_window(_KINDS[kind], WINDOWS_FIR[window], beta, _fp(t), int(n), f1, f2))
     return t
 
 
-def fir_lowpass(n, cutoff, window="blackman"):
-    return fir_design("lowpass", n, cutoff, 0.0, window)
+def fir_lowpass(n, cutoff, window="blackman", beta=0.5):
+    return fir_design("lowpass", n, cutoff, 0.0, window, beta)
 
 
-def fir_highpass(n, cutoff, window="blackman"):
-    return fir_design("highpass", n, cutoff, 0.0, window)
+def fir_highpass(n, cutoff, window="blackman", beta=0.5):
+    return fir_design("highpass", n, cutoff, 0.0, window, beta)
 
 
-def fir_bandpass(n, f1, f2, window="blackman"):
-    return fir_design("bandpass", n, f1, f2, window)
+def fir_bandpass(n, f1, f2, window="blackman", beta=0.5):
+    return fir_design("bandpass", n, f1, f2, window, beta)
 
 
-def fir_bandstop(n, f1, f2, window="blackman"):
-    return fir_design("bandstop", n, f1, f2, window)
+def fir_bandstop(n, f1, f2, window="blackman", beta=0.5):
+    return fir_design("bandstop", n, f1, f2, window, beta)
 
 
 def host_alloc(nbytes):

@@ -42,12 +42,42 @@ std::vector<float> blackman(size_t n) {
 // The other windows a design can take, over the same grid t_i = i/(n-1)
 // (libs/kfr/dsp/window.hpp:120-139 rectangular, :204-223 hann, :247-267 hamming with
 // alpha 0.54, :314-334 blackman_harris).
-bool design_window(int window, size_t n, std::vector<float>& w) {
+// kfr::modzerobessel in fp32 (libs/kfr/base/modzerobessel.hpp:42-94): I0 by its power series
+// sum_k ((x/2)^2)^k / (k!)^2, 1 + q and twenty further terms accumulated in fp32.
+float bessel_i0(float x) {
+    const float half = x * 0.5f, q = half * half;
+    float power = q, sum = 1.0f + q;
+    double factorial = 1.0;
+    for (int k = 2; k < 22; ++k) {
+        factorial *= k;
+        power *= q;
+        sum = power * static_cast<float>(1.0 / (factorial * factorial)) + sum;
+    }
+    return sum;
+}
+
+// kfr::window_kaiser (libs/kfr/dsp/window.hpp:336-358) on t_i = -1 + i * 2/(n-1)
+std::vector<float> kaiser(size_t n, float beta) {
+    std::vector<float> w(n);
+    const float norm = 1.0f / bessel_i0(beta);
+    const float step = 2.0f / static_cast<float>(n - 1);
+    for (size_t i = 0; i < n; ++i) {
+        const float t = -1.0f + static_cast<float>(static_cast<int64_t>(i)) * step;
+        w[i] = bessel_i0(beta * std::sqrt(1.0f - t * t)) * norm;
+    }
+    return w;
+}
+
+bool design_window(int window, float param, size_t n, std::vector<float>& w) {
     if (window == SDR_WINDOW_BLACKMAN) {
         w = blackman(n);
         return true;
     }
-    if (window < SDR_WINDOW_BLACKMAN || window > SDR_WINDOW_BLACKMAN_HARRIS) return false;
+    if (window == SDR_WINDOW_KAISER) {
+        w = kaiser(n, param);
+        return true;
+    }
+    if (window < SDR_WINDOW_BLACKMAN || window > SDR_WINDOW_KAISER) return false;
     w.resize(n);
     const float step = 1.0f / static_cast<float>(n - 1);
     for (size_t i = 0; i < n; ++i) {
@@ -104,14 +134,15 @@ extern "C" int sdr_hilbert_taps(float* taps, size_t n) {
 }
 
 extern "C" int sdr_fir_design(int kind, float* taps, size_t n, float f1, float f2) {
-    return sdr_fir_design_window(kind, SDR_WINDOW_BLACKMAN, taps, n, f1, f2);
+    return sdr_fir_design_window(kind, SDR_WINDOW_BLACKMAN, 0.0f, taps, n, f1, f2);
 }
 
-extern "C" int sdr_fir_design_window(int kind, int window, float* taps, size_t n, float f1, float f2) {
+extern "C" int sdr_fir_design_window(int kind, int window, float window_param, float* taps, size_t n, float f1,
+                                     float f2) {
     if (!taps || n < 2) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: need taps and n >= 2");
     if (kind < SDR_LOWPASS || kind > SDR_BANDSTOP) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: unknown kind");
     std::vector<float> w;
-    if (!design_window(window, n, w)) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: unknown window");
+    if (!design_window(window, window_param, n, w)) return sdr_amd::fail(SDR_ERR_INVALID, "sdr_fir_design: unknown window");
     const bool odd = n & 1;
     if (kind == SDR_LOWPASS || kind == SDR_HIGHPASS) {
         // fir_design.hpp:38-44 and :55-61

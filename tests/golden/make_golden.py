@@ -70,9 +70,17 @@ for wname in ("rectangular", "hann", "hamming", "blackman_harris", "blackman"):
                             ("bandstop", 65, 0.1, 0.3)):
         out, _, _ = run(["ref_harness", "taps", kind, str(n), repr(f1), repr(f2), wname])
         taps["%s_%d_%g_%g_%s" % (kind, n, f1, f2, wname)] = np.frombuffer(out, np.float32)
+# the Kaiser window (one parameter, beta) and designs under it
+for n, beta in ((9, 3.0), (64, 0.5), (127, 8.6), (1000, 14.0)):
+    out, _, _ = run(["ref_harness", "window", "kaiser", str(n), repr(beta)])
+    taps["window_kaiser%g_%d" % (beta, n)] = np.frombuffer(out, np.float32)
+for kind, n, f1, f2, beta in (("lowpass", 127, 0.1, 0.0, 8.6), ("highpass", 63, 0.2, 0.0, 3.0),
+                              ("bandpass", 255, 0.05, 0.15, 5.0), ("bandstop", 65, 0.1, 0.3, 0.5)):
+    out, _, _ = run(["ref_harness", "taps", kind, str(n), repr(f1), repr(f2), "kaiser", repr(beta)])
+    taps["%s_%d_%g_%g_kaiser%g" % (kind, n, f1, f2, beta)] = np.frombuffer(out, np.float32)
 save("taps.npz", **taps)
 manifest["taps.npz"] = ("ref_harness taps hilbert N ; ref_harness taps KIND N F1 F2 [WINDOW] (key = KIND_N_F1_F2[_WINDOW]) ; "
-                        "ref_harness window NAME N (key = window_NAME_N)")
+                        "ref_harness window NAME N [BETA] (key = window_NAME_N; kaiserBETA for the Kaiser window)")
 
 # ---- (ii) gen ----------------------------------------------------------------
 gens = {

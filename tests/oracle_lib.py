@@ -39,6 +39,10 @@ def lib():
         L.sdro_window.restype = C.c_int
         L.sdro_fir_design_window.argtypes = [C.c_int, C.c_int, fp, C.c_size_t, C.c_float, C.c_float]
         L.sdro_fir_design_window.restype = C.c_int
+        L.sdro_window_param.argtypes = [C.c_int, C.c_float, fp, C.c_size_t]
+        L.sdro_window_param.restype = C.c_int
+        L.sdro_fir_design_window_param.argtypes = [C.c_int, C.c_int, C.c_float, fp, C.c_size_t, C.c_float, C.c_float]
+        L.sdro_fir_design_window_param.restype = C.c_int
         L.sdro_fir_create.argtypes = [fp, C.c_size_t, C.c_int, C.c_int]
         L.sdro_fir_create.restype = C.c_void_p
         L.sdro_fir_reset.argtypes = [C.c_void_p]
@@ -83,18 +87,18 @@ def hilbert_taps(n):
 FIR_KINDS = {"lowpass": 0, "highpass": 1, "bandpass": 2, "bandstop": 3}
 
 
-WINDOWS = {"blackman": 0, "rectangular": 1, "hann": 2, "hamming": 3, "blackman_harris": 4}
+WINDOWS = {"blackman": 0, "rectangular": 1, "hann": 2, "hamming": 3, "blackman_harris": 4, "kaiser": 5}
 
 
-def fir_design(kind, n, f1, f2=0.0, window="blackman"):
+def fir_design(kind, n, f1, f2=0.0, window="blackman", param=0.5):
     t = np.empty(n, np.float32)
-    assert lib().sdro_fir_design_window(FIR_KINDS[kind], WINDOWS[window], _fp(t), n, f1, f2) == 0
+    assert lib().sdro_fir_design_window_param(FIR_KINDS[kind], WINDOWS[window], param, _fp(t), n, f1, f2) == 0
     return t
 
 
-def window(name, n):
+def window(name, n, param=0.5):
     w = np.empty(n, np.float32)
-    assert lib().sdro_window(WINDOWS[name], _fp(w), n) == 0
+    assert lib().sdro_window_param(WINDOWS[name], param, _fp(w), n) == 0
     return w
 
 

@@ -238,7 +238,8 @@ def test_stream_filter_fir_extension(golden_dir):
 
 @pytest.mark.parametrize("kind,args,window", [
     ("lowpass", ["cutoff=0.1"], "hann"), ("bandpass", ["cutoff=0.05", "cutoff2=0.15"], "hamming"),
-    ("highpass", ["cutoff=0.2"], "blackman_harris"), ("bandstop", ["cutoff=0.1", "cutoff2=0.3"], "rectangular")])
+    ("highpass", ["cutoff=0.2"], "blackman_harris"), ("bandstop", ["cutoff=0.1", "cutoff2=0.3"], "rectangular"),
+    ("lowpass", ["cutoff=0.12", "beta=8.6"], "kaiser")])
 def test_stream_filter_fir_extension_windows(kind, args, window):
     """fir= under the other kfr windows (window=...): the block's output against the oracle's
     FIR run with the oracle's design for that window (both pinned to the reference's own taps
@@ -246,14 +247,14 @@ def test_stream_filter_fir_extension_windows(kind, args, window):
     rng = np.random.default_rng(31)
     n, ntaps = 9000, 63
     x = rng.uniform(-1, 1, n).astype(np.float32)
-    f = {"cutoff": 0.0, "cutoff2": 0.0}
+    f = {"cutoff": 0.0, "cutoff2": 0.0, "beta": 0.5}
     f.update({a.split("=")[0]: float(a.split("=")[1]) for a in args})
-    taps = O.fir_design(kind, ntaps, f["cutoff"], f["cutoff2"], window)
+    taps = O.fir_design(kind, ntaps, f["cutoff"], f["cutoff2"], window, f["beta"])
     inp = b"".join(O.pack_packet(0, O.SIGNAL, x[i:i + 1500].tobytes(), 1500) for i in range(0, n, 1500))
     out = run_block("stream-filter", ["pass", "fir=" + kind, "taps=%d" % ntaps, "window=" + window] + args, inp)
     got = O.parse_packets(out)
     assert [p[:3] for p in got] == [(0, O.SIGNAL, 6000)] * 6
     assert rel_err(samples(got), O.fir(taps, x)) <= TOL
-    p = subprocess.run([os.path.join(BIN, "stream-filter"), "pass", "fir=lowpass", "cutoff=0.1", "window=kaiser"], input=b"",
+    p = subprocess.run([os.path.join(BIN, "stream-filter"), "pass", "fir=lowpass", "cutoff=0.1", "window=gaussian"], input=b"",
                        capture_output=True)
     assert p.returncode == 255 and b"window" in p.stderr

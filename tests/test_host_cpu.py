@@ -58,14 +58,17 @@ def test_tap_designers_match_reference_golden(golden_dir):
             continue        # (the windows themselves are pinned on the oracle; the library exports only designs)
         else:
             window = "_".join(parts[4:]) or "blackman"
-            got = sdr_amd.fir_design(parts[0], int(parts[1]), float(parts[2]), float(parts[3]), window)
+            beta = 0.5
+            if window.startswith("kaiser"):
+                window, beta = "kaiser", float(window[len("kaiser"):])
+            got = sdr_amd.fir_design(parts[0], int(parts[1]), float(parts[2]), float(parts[3]), window, beta)
             # the library's taps are the oracle's, bit for bit (same fp32 recipe, same libm)
-            assert np.array_equal(got, O.fir_design(parts[0], int(parts[1]), float(parts[2]), float(parts[3]), window)), key
+            assert np.array_equal(got, O.fir_design(parts[0], int(parts[1]), float(parts[2]), float(parts[3]), window, beta)), key
         # (other windows: KFR's own fp32 cosine is off by up to 1e-6 near 3 pi / 2)
         tol = 5e-7 if len(parts) <= 4 else 1e-6
         assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), key
     with pytest.raises(sdr_amd.SdrError):
-        sdr_amd._capi._check(sdr_amd.lib().sdr_fir_design_window(0, 9, sdr_amd._capi._fp(np.zeros(8, np.float32)), 8, 0.1, 0.0))
+        sdr_amd._capi._check(sdr_amd.lib().sdr_fir_design_window(0, 9, 0.5, sdr_amd._capi._fp(np.zeros(8, np.float32)), 8, 0.1, 0.0))
 
 
 def test_optimal_block_size():

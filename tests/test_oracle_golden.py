@@ -44,20 +44,27 @@ def test_hilbert_taps(taps, n):
     assert np.max(np.abs(got - ref)) <= 2e-7 * np.max(np.abs(ref))
 
 
+def split_window(name):
+    """golden key suffix -> (window, parameter): 'kaiser8.6' -> ('kaiser', 8.6)"""
+    if name.startswith("kaiser"):
+        return "kaiser", float(name[len("kaiser"):])
+    return name, 0.5
+
+
 def test_fir_designs(taps):
     n_checked = 0
     for key, ref in taps.items():
         if key.startswith("hilbert") or key.startswith("window"):
             continue
         kind, n, f1, f2 = key.split("_")[:4]
-        window = "_".join(key.split("_")[4:]) or "blackman"
-        got = O.fir_design(kind, int(n), float(f1), float(f2), window)
+        window, param = split_window("_".join(key.split("_")[4:]) or "blackman")
+        got = O.fir_design(kind, int(n), float(f1), float(f2), window, param)
         # (Blackman designs to 5e-7; under the other windows KFR's own fp32 cosine shows:
         # it is off by up to 1e-6 near 3 pi / 2, the oracle uses libm's)
         tol = 5e-7 if window == "blackman" else 1e-6
         assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), key
         n_checked += 1
-    assert n_checked == 6 + 4 * 4
+    assert n_checked == 6 + 4 * 4 + 4
 
 
 def test_windows(taps):
@@ -67,10 +74,11 @@ def test_windows(taps):
         if not key.startswith("window_"):
             continue
         name, n = key[len("window_"):].rsplit("_", 1)
-        got = O.window(name, int(n))
+        name, param = split_window(name)
+        got = O.window(name, int(n), param)
         assert np.max(np.abs(got - ref)) <= 6e-7, key      # (KFR's fp32 cosine, see above)
         n_checked += 1
-    assert n_checked == 5 * 4
+    assert n_checked == 5 * 4 + 4
 
 
 def test_fir_vs_kfr(golden_dir):
