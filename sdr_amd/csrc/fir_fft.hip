@@ -474,9 +474,12 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = nx[GEN ? 0 : i];
         }
-        // past the end the workgroup re-loads its own tile (harmless): keeps the body branch-free
+        // past its last tile a workgroup prefetches the first interior tile of the call -- loads
+        // that nobody consumes, which keeps the body branch-free; one tile shared by every
+        // workgroup stays in L2, where re-loading the workgroup's own tile went out to memory
+        // (2304 x 32 KB per C2 launch)
         Pos nxt = advance(cur);
-        if (runs ? left <= 1 : nxt.ch >= a.channels) nxt = cur;
+        if (runs ? left <= 1 : nxt.ch >= a.channels) nxt = Pos{0, a.t_lo};
         const float* pn = in_ptr(nxt);
         f2 w[16];
         if (a.ablate & 1) {
