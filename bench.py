@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="auto", choices=["auto", "direct", "fft", "fft_once"],
+                    help="experiments: pin the kernel family (the default is the library's own choice)")
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--chunk-log2", type=int, default=29, help="c5: samples per call")
     ap.add_argument("--unfused", action="store_true", help="c5: generator kernel + chain kernel through an HBM buffer")
@@ -247,7 +249,7 @@ def main():
     taps = mk_taps(S)
     n = 1 << log2n
     w = 2 if cplx else 1
-    st = S.FirState(taps, cplx, channels=channels, device=local_rank)
+    st = S.FirState(taps, cplx, channels=channels, device=local_rank, path=args.path)
 
     from sdr_amd import sharding
     x = torch.empty((channels * n, w), dtype=torch.float32, device=dev)

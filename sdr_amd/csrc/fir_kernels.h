@@ -45,7 +45,7 @@ struct FftArgs {
     long long channels;
     int halo;             // old samples per tile: >= ntaps-1; 64 * {1,2,4,8,16,32}
     int hist_len;         // >= halo
-    int ablate;           // diagnostics (SDR_AMD_FFT_ABLATE): 1 = skip the arithmetic (memory pattern only)
+    int ablate;           // read by -DSDR_AMD_DIAG builds only: 1 = skip the arithmetic (memory pattern only)
     int parts;            // filter partitions of 2048 taps (1 = plain overlap-save)
     int contig;           // every workgroup walks a contiguous run of tiles instead of a grid-strided set
     float* new_hist;      // [channels][hist_len]: receives the history after this call (NULL: not carried)
@@ -56,6 +56,19 @@ struct FftArgs {
 hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
 const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);
+
+// kernel families a handle can be pinned to (internal; the public create chooses by tap count)
+enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1 };
+
+// direct-form plan of a tap vector (sdr_capi.hip: plan_direct)
+struct DirectPlan {
+    const KernelInfo* k = nullptr;
+    int stride = 1, shift = 0, R = 8, nchunks = 2, hist_len = 0;
+    size_t kept = 0;        // taps the kernel applies (every stride-th)
+    size_t taps_floats = 0; // compacted taps, zero-padded: nchunks * R / stride
+};
+int plan_direct(const float* taps, size_t ntaps, int sample_kind, DirectPlan* p);
+void plan_direct_fill(const float* taps, const DirectPlan& p, float* g);
 
 const KernelInfo* find_kernel(int R, int stride, bool real);
 size_t kernel_lds_bytes(const KernelInfo& k, int nchunks);

@@ -8,6 +8,23 @@
 
 namespace sdr_amd {
 
+// Makes `device` current for the scope, restores the caller's device after.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
 // Like sdr_fir_process_device with the generator's next `blocks` packets as the input,
 // synthesised inside the FIR kernel (nothing is written but the blocks*B outputs).
 // Needs the overlap-save path, real samples, one channel, 256 <= B <= 2^23.

@@ -39,23 +39,6 @@ static int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return sdr_amd::hip_fail(e_, #expr); \
     } while (0)
 
-// Makes `device` current for the scope, restores the caller's device after.
-struct DeviceGuard {
-    int prev = -1;
-    bool changed = false;
-    hipError_t err = hipSuccess;
-    explicit DeviceGuard(int device) {
-        err = hipGetDevice(&prev);
-        if (err == hipSuccess && prev != device) {
-            err = hipSetDevice(device);
-            changed = err == hipSuccess;
-        }
-    }
-    ~DeviceGuard() {
-        if (changed) (void)hipSetDevice(prev);
-    }
-};
-
 } // namespace sdr_amd
 
 using namespace sdr_amd;
@@ -99,30 +82,23 @@ extern "C" int sdr_device_count(void) {
     return n;
 }
 
+// Diagnostic builds only (make diag -> libsdr_amd_diag.so, used by scripts/exp): kernel-family,
+// tile and grid overrides from the environment.  The release library reads no environment
+// variable on the compute path and has no switch that skips arithmetic.
+#ifdef SDR_AMD_DIAG
 static int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
 }
+#else
+static inline int env_int(const char*, int dflt) { return dflt; }
+#endif
 
-// force_path: -1 = choose by tap count (and SDR_AMD_FFT), 0 = direct form, 1 = overlap-save
-static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind, size_t channels,
-                           int device, int force_path) {
-    clear_error();
-    if (!out) return fail(SDR_ERR_INVALID, "sdr_fir_create: out is NULL");
-    *out = nullptr;
-    if (!taps || ntaps == 0) return fail(SDR_ERR_INVALID, "sdr_fir_create: no taps");
-    if (ntaps > SDR_MAX_TAPS) return fail(SDR_ERR_INVALID, "sdr_fir_create: more than SDR_MAX_TAPS (131072) taps");
-    if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
-        return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
-    if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0)
-        return fail(SDR_ERR_NO_DEVICE, "sdr_fir_create: no HIP device (libsdr_amd has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(SDR_ERR_INVALID, "sdr_fir_create: device out of range");
-
-    // Tap structure: every other tap zero (Hilbert transformer, reference
-    // include/sdr/hilbert.hpp:46-55) => a kernel that skips them.
+// Direct-form plan for a tap vector: tap structure (every other tap zero => a kernel that skips
+// them: the Hilbert transformer, reference include/sdr/hilbert.hpp:46-55), outputs per lane,
+// chunk count.  plan_direct_fill writes the compacted taps g[i] = h[stride*i + shift], zero-padded
+// to whole chunk pairs (plan.taps_floats floats).  Neither touches the heap on success.
+int sdr_amd::plan_direct(const float* taps, size_t ntaps, int sample_kind, DirectPlan* p) {
     bool odd_zero = ntaps >= 8, even_zero = ntaps >= 8;
     for (size_t j = 0; j < ntaps; ++j) {
         if (taps[j] != 0.0f) {
@@ -134,10 +110,63 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if (odd_zero && !even_zero) stride = 2, shift = 0;
     else if (even_zero && !odd_zero) stride = 2, shift = 1;
     if (env_int("SDR_AMD_DENSE", 0)) stride = 1, shift = 0;
+    const size_t kept = (ntaps - shift + stride - 1) / stride;
+    // Outputs per lane: 4 (8 KB tiles, more workgroups in flight: 5.9-6.0 TB/s) while the filter
+    // is short enough to stay memory-bound that way, else 8 (profiles/r01_direct_r_sweep.txt)
+    const int R = env_int("SDR_AMD_R", kept <= 31 ? 4 : 8);
+    if (R != 4 && R != 8 && R != 16) return fail(SDR_ERR_INVALID, "SDR_AMD_R must be 4, 8 or 16");
+    const KernelInfo* k = find_kernel(R, stride, sample_kind == SDR_REAL);
+    if (!k) return fail(SDR_ERR_INVALID, "sdr_fir_create: no kernel for this configuration");
+    const size_t span = (kept - 1) * stride + 1; // sample offsets covered
+    int nchunks = (int)((span + R - 1) / R);
+    nchunks += nchunks & 1;
+    if (nchunks < 2) nchunks = 2;
+    p->k = k;
+    p->stride = stride;
+    p->shift = shift;
+    p->R = R;
+    p->nchunks = nchunks;
+    p->hist_len = nchunks * R + 4;
+    p->kept = kept;
+    p->taps_floats = (size_t)nchunks * (R / stride);
+    return SDR_OK;
+}
+
+void sdr_amd::plan_direct_fill(const float* taps, const DirectPlan& p, float* g) {
+    for (size_t i = 0; i < p.taps_floats; ++i) g[i] = i < p.kept ? taps[p.stride * i + p.shift] : 0.0f;
+}
+
+// path: SDR_PATH_AUTO = choose by tap count (measured crossovers), or one kernel family forced
+// (internal callers and the test hook below; the public sdr_fir_create always passes AUTO).
+// grid: workgroups of the persistent overlap-save kernels (0 = the default for the device).
+static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind, size_t channels,
+                           int device, int path, int grid) {
+    clear_error();
+    if (!out) return fail(SDR_ERR_INVALID, "sdr_fir_create: out is NULL");
+    *out = nullptr;
+    if (!taps || ntaps == 0) return fail(SDR_ERR_INVALID, "sdr_fir_create: no taps");
+    if (ntaps > SDR_MAX_TAPS) return fail(SDR_ERR_INVALID, "sdr_fir_create: more than SDR_MAX_TAPS (131072) taps");
+    if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
+        return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
+    if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
+    if (path < SDR_PATH_AUTO || path > SDR_PATH_FFT) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(SDR_ERR_NO_DEVICE, "sdr_fir_create: no HIP device (libsdr_amd has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SDR_ERR_INVALID, "sdr_fir_create: device out of range");
+
+    DirectPlan plan;
+    int prc = plan_direct(taps, ntaps, sample_kind, &plan);
+    if (prc != SDR_OK) return prc;
+    const int stride = plan.stride, shift = plan.shift, nchunks = plan.nchunks;
+    const KernelInfo* k = plan.k;
+    std::vector<float> g(plan.taps_floats);
+    plan_direct_fill(taps, plan, g.data());
 
     // Path choice.  Direct form: ntaps (or ntaps/2 with the Hilbert structure) packed
     // FMAs per complex sample; overlap-save FFT (N = 4096): ~50 packed ops per sample
-    // times 4096/(4096-halo).  SDR_AMD_FFT=0/1 forces the choice.
+    // times 4096/(4096-halo).
     int fft_halo = 0, fft_parts = 1;
     fir_fft_plan(ntaps, &fft_halo, &fft_parts);
     // Measured crossover (profiles/r01_direct_vs_fft_crossover.txt): the direct form holds
@@ -145,25 +174,10 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // Hilbert-structured taps; from there the fast convolution is quicker.
     const size_t fft_from = stride == 2 ? 88u : sample_kind == SDR_COMPLEX ? 33u : 41u;
     bool use_fft = ntaps >= fft_from && fft_parts <= 64;
-    if (const char* e = getenv("SDR_AMD_FFT")) use_fft = atoi(e) != 0 && fft_parts <= 64;
-    if (force_path >= 0) use_fft = force_path != 0 && fft_parts <= 64;
-
-    // compacted taps g[i] = h[stride*i + shift], zero-padded to whole chunk pairs
-    const size_t kept = (ntaps - shift + stride - 1) / stride;
-    // Outputs per lane: 4 (8 KB tiles, more workgroups in flight: 5.9-6.0 TB/s) while the filter
-    // is short enough to stay memory-bound that way, else 8 (profiles/r01_direct_r_sweep.txt)
-    int R = env_int("SDR_AMD_R", kept <= 31 ? 4 : 8);
-    if (R != 4 && R != 8 && R != 16) return fail(SDR_ERR_INVALID, "SDR_AMD_R must be 4, 8 or 16");
-    const KernelInfo* k = find_kernel(R, stride, sample_kind == SDR_REAL);
-    if (!k) return fail(SDR_ERR_INVALID, "sdr_fir_create: no kernel for this configuration");
-
-    const size_t span = (kept - 1) * stride + 1; // sample offsets covered
-    int nchunks = (int)((span + R - 1) / R);
-    nchunks += nchunks & 1;
-    if (nchunks < 2) nchunks = 2;
-    const size_t per_chunk = R / stride;
-    std::vector<float> g((size_t)nchunks * per_chunk, 0.0f);
-    for (size_t i = 0; i < kept; ++i) g[i] = taps[stride * i + shift];
+#ifdef SDR_AMD_DIAG
+    if (const char* ev = getenv("SDR_AMD_FFT")) use_fft = atoi(ev) != 0 && fft_parts <= 64;
+#endif
+    if (path != SDR_PATH_AUTO) use_fft = path != SDR_PATH_DIRECT && fft_parts <= 64;
 
     sdr_fir* f = new (std::nothrow) sdr_fir();
     if (!f) return fail(SDR_ERR_NOMEM, "sdr_fir_create: out of memory");
@@ -175,7 +189,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     f->k = k;
     f->nchunks = nchunks;
     f->shift = shift;
-    f->hist_len = nchunks * R + 4;
+    f->hist_len = plan.hist_len;
     f->use_fft = use_fft;
     if (use_fft) {
         f->fft_halo = fft_halo;
@@ -242,7 +256,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         // them leave a shorter tail than two (same-box sweep: 9 per CU 1 % ahead of 6, 12 and 16 level)
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 9);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
-        f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", f->fft_grid));
+        f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", grid > 0 ? grid : f->fft_grid));
         f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
         f->fft_contig = env_int("SDR_AMD_FFT_CONTIG", 0);
     }
@@ -257,12 +271,20 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
 
 extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
                               size_t channels, int device) {
-    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, -1);
+    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, SDR_PATH_AUTO, 0);
+}
+
+// Test hook (declared in csrc/internal.h, not part of include/sdr_amd.h): sdr_fir_create with the
+// kernel family and the persistent grid chosen by the caller, so that parity tests can hold every
+// family to its parity bar at every tap count without any environment switch in the library.
+extern "C" int sdr_amd_internal_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                                           size_t channels, int device, int path, int grid) {
+    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, path, grid);
 }
 
 int sdr_amd::fir_create_overlap_save(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
                                      size_t channels, int device) {
-    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, 1);
+    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, SDR_PATH_FFT, 0);
 }
 
 bool sdr_amd::fir_uses_overlap_save(const sdr_fir_t* f) { return f && f->use_fft; }

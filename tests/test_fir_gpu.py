@@ -53,30 +53,19 @@ CASES = [
 ]
 
 
-@pytest.fixture
-def force_path(monkeypatch):
-    """Select the kernel family regardless of the tap-count heuristic: the library
-    reads SDR_AMD_FFT when a state is created ("0" direct form, "1" overlap-save FFT)."""
-    def _set(path):
-        if path == "auto":
-            monkeypatch.delenv("SDR_AMD_FFT", raising=False)
-        else:
-            monkeypatch.setenv("SDR_AMD_FFT", "1" if path == "fft" else "0")
-    return _set
-
-
 @pytest.mark.parametrize("path", ["direct", "fft"])
 @pytest.mark.parametrize("kind,ntaps,cplx", [("lowpass", 127, True), ("lowpass", 127, False), ("hilbert", 127, False),
                                              ("hilbert", 128, True), ("lowpass", 255, True), ("random", 16, False),
                                              ("random", 2, True), ("lowpass", 1000, False), ("bandpass", 4095, True)])
-def test_both_kernel_families(force_path, path, kind, ntaps, cplx):
-    """Every tap count runs on both the direct-form and the overlap-save FFT kernels."""
-    force_path(path)
+def test_both_kernel_families(path, kind, ntaps, cplx):
+    """Every tap count runs on both the direct-form and the overlap-save FFT kernels, pinned
+    through the library's internal create hook (sdr_amd/csrc/internal.h) -- the release library
+    has no environment switch."""
     rng = np.random.default_rng(ntaps + 3 * cplx)
     taps = taps_for(kind, ntaps)
     n = 33333
     x = rand(rng, n, cplx)
-    st = sdr_amd.FirState(taps, cplx)
+    st = sdr_amd.FirState(taps, cplx, path=path)
     assert ("fft" in st.kernel_name) == (path == "fft"), st.kernel_name
     cuts = [0, 1, 4000, 4001, 12288, 20000, n]   # tile-sized, tiny and ragged calls
     y = np.concatenate([sdr_amd.fir(st, x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
@@ -113,17 +102,15 @@ def test_very_long_filters(ntaps, n):
 
 @pytest.mark.parametrize("grid", [3, 7, 0])
 @pytest.mark.parametrize("ntaps,cplx", [(4095, True), (4095, False), (2050, False), (3001, True)])
-def test_two_partition_spectrum_cache(monkeypatch, ntaps, cplx, grid):
+def test_two_partition_spectrum_cache(ntaps, cplx, grid):
     """2050..4096 taps: every workgroup walks a contiguous run of tiles and reuses the
     previous tile's spectrum.  A grid of 3 or 7 workgroups makes the runs long and makes
     them cross channel boundaries (where the cached spectrum must be rebuilt)."""
-    if grid:
-        monkeypatch.setenv("SDR_AMD_FFT_GRID", str(grid))
     rng = np.random.default_rng(ntaps + grid)
     taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps)).astype(np.float32)
     C, n = 5, 50000
     x = np.stack([rand(rng, n, cplx) for _ in range(C)])
-    st = sdr_amd.FirState(taps, cplx, channels=C)
+    st = sdr_amd.FirState(taps, cplx, channels=C, grid=grid)
     y = np.concatenate([sdr_amd.fir(st, x[:, :30001]), sdr_amd.fir(st, x[:, 30001:])], axis=1)
     for c in range(C):
         assert rel_err(y[c], O.fir(taps, x[c])) <= TOL, c
