@@ -39,6 +39,8 @@ def lib():
         L.sdr_fir_design.argtypes = [C.c_int, fp, sz, C.c_float, C.c_float]
         L.sdr_fir_design_window.argtypes = [C.c_int, C.c_int, C.c_float, fp, sz, C.c_float, C.c_float]
         L.sdr_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int]
+        # test hook outside the C ABI (sdr_amd/csrc/internal.h): pins the kernel family
+        L.sdr_amd_internal_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int, C.c_int, C.c_int]
         L.sdr_fir_process_device.argtypes = [vp, vp, sz, sz, vp, sz, vp]
         L.sdr_fir_process.argtypes = [vp, vp, sz, vp]
         L.sdr_fir_submit.argtypes = [vp, C.c_int, vp, sz, vp]
@@ -144,15 +146,23 @@ class FirState:
     `channels` independent streams.  History is zero after construction and is
     carried from call to call, like kfr::fir_state in the reference."""
 
-    def __init__(self, taps, complex_samples=False, channels=1, device=0):
+    PATHS = {"auto": -1, "direct": 0, "fft": 1}
+
+    def __init__(self, taps, complex_samples=False, channels=1, device=0, path="auto", grid=0):
+        """path / grid: tests and experiments only -- pin the kernel family ("direct", "fft" =
+        overlap-save) and the persistent grid
+        through the library's internal hook; the default goes through sdr_fir_create."""
         taps = np.ascontiguousarray(taps, np.float32)
         self.complex_samples = bool(complex_samples)
         self.channels = int(channels)
         self.device = int(device)
         self._h = C.c_void_p()
-        _check(lib().sdr_fir_create(C.byref(self._h), _fp(taps), len(taps),
-                                    SDR_COMPLEX if self.complex_samples else SDR_REAL,
-                                    self.channels, self.device))
+        kind = SDR_COMPLEX if self.complex_samples else SDR_REAL
+        if path == "auto" and not grid:
+            _check(lib().sdr_fir_create(C.byref(self._h), _fp(taps), len(taps), kind, self.channels, self.device))
+        else:
+            _check(lib().sdr_amd_internal_fir_create(C.byref(self._h), _fp(taps), len(taps), kind, self.channels,
+                                                     self.device, self.PATHS[path], int(grid)))
 
     # -- introspection
     @property
@@ -280,7 +290,14 @@ class Chain:
         assert x.is_cuda and x.is_contiguous()
         if out is None:
             out = torch.empty_like(x)
-        n = x.shape[-2] if self.complex_samples else x.shape[-1]
+        assert out.is_cuda and out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype
+        if self.complex_samples:
+            n = x.shape[-1] if x.is_complex() else x.shape[-2]
+        else:
+            n = x.shape[-1]
+        per = x.numel() if x.is_complex() or not self.complex_samples else x.numel() // 2
+        if per != n * self.channels:
+            raise ValueError("tensor shape does not match %d channel(s)" % self.channels)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         n_out = self.process_device(x.data_ptr(), n, out.data_ptr(), stream=stream)
         return out, n_out
