@@ -107,6 +107,23 @@ int sdr_fir_process(sdr_fir_t* f, const void* in, size_t n, void* out);
 int sdr_fir_submit(sdr_fir_t* f, int slot, const void* in, size_t n, void* out);
 int sdr_fir_wait(sdr_fir_t* f, int slot);
 
+/* No counterpart in the reference: the same filter as sdr_fir_create + one
+ * sdr_fir_process_device on a fresh handle (zero history, one channel: y[i] = sum_j h[j] x[i-j],
+ * x[<0] = 0), as ONE stateless call that allocates nothing -- no hipMalloc / hipFree, no host
+ * heap on the success path -- for callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid it.  The taps travel as a kernel argument; the
+ * compacted taps and the (zero) history the kernels read live in a fixed 8 KiB device array
+ * inside the library (one copy per GPU, held until the process ends).  Limits, refused with
+ * SDR_ERR_INVALID: 1..SDR_NOALLOC_MAX_TAPS taps (the direct-form kernels),
+ * n <= SDR_NOALLOC_MAX_SAMPLES.  d_in / d_out are DEVICE memory on `device`, must not overlap;
+ * asynchronous on hip_stream.  Calls on one GPU share the array: back-to-back calls on one
+ * stream are fine, calls that overlap in time on one GPU (two streams or threads) race. */
+#define SDR_NOALLOC_MAX_TAPS 255
+#define SDR_NOALLOC_MAX_SAMPLES ((size_t)1 << 36)
+#define SDR_NOALLOC_SCRATCH_BYTES 8192
+int sdr_fir_apply_device_noalloc(const float* taps, size_t ntaps, int sample_kind, const void* d_in,
+                                 size_t n, void* d_out, int device, void* hip_stream);
+
 /* Replaces kfr::filter_fir::reset (reference libs/kfr/dsp/fir.hpp:195-199):
  * zero the history of every channel. */
 int sdr_fir_reset(sdr_fir_t* f);

@@ -15,8 +15,10 @@ compute calls raise.
 """
 from ._capi import (SdrError, FirState, fir, hilbert, fir_lowpass, fir_highpass, fir_bandpass,
                     fir_bandstop, fir_design, lib, lib_path, device_count, version,
-                    host_alloc, host_free, SDR_REAL, SDR_COMPLEX, Chain, Gen, optimal_block_size, WAVEFORMS)
+                    host_alloc, host_free, SDR_REAL, SDR_COMPLEX, Chain, Gen, optimal_block_size, WAVEFORMS,
+                    fir_apply_device_noalloc)
 
 __all__ = ["SdrError", "FirState", "fir", "hilbert", "fir_lowpass", "fir_highpass", "fir_bandpass",
            "fir_bandstop", "fir_design", "lib", "lib_path", "device_count", "version",
-           "host_alloc", "host_free", "SDR_REAL", "SDR_COMPLEX", "Chain", "Gen", "optimal_block_size", "WAVEFORMS"]
+           "host_alloc", "host_free", "SDR_REAL", "SDR_COMPLEX", "Chain", "Gen", "optimal_block_size", "WAVEFORMS",
+           "fir_apply_device_noalloc"]

@@ -42,6 +42,7 @@ def lib():
         # test hook outside the C ABI (sdr_amd/csrc/internal.h): pins the kernel family
         L.sdr_amd_internal_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int, C.c_int, C.c_int]
         L.sdr_fir_process_device.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+        L.sdr_fir_apply_device_noalloc.argtypes = [fp, sz, C.c_int, vp, sz, vp, C.c_int, vp]
         L.sdr_fir_process.argtypes = [vp, vp, sz, vp]
         L.sdr_fir_submit.argtypes = [vp, C.c_int, vp, sz, vp]
         L.sdr_fir_wait.argtypes = [vp, C.c_int]
@@ -238,6 +239,14 @@ class FirState:
             self.close()
         except Exception:
             pass
+
+
+def fir_apply_device_noalloc(taps, complex_samples, d_in, n, d_out, device=0, stream=None):
+    """sdr_fir_apply_device_noalloc: stateless one-shot FIR on raw device pointers that allocates
+    nothing (<= 255 taps; zero history)."""
+    taps = np.ascontiguousarray(taps, np.float32)
+    _check(lib().sdr_fir_apply_device_noalloc(_fp(taps), len(taps), SDR_COMPLEX if complex_samples else SDR_REAL,
+                                              d_in, int(n), d_out, int(device), C.c_void_p(stream or 0)))
 
 
 def fir(state, x):
