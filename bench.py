@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--chunk-log2", type=int, default=29, help="c5: samples per call")
     ap.add_argument("--unfused", action="store_true", help="c5: generator kernel + chain kernel through an HBM buffer")
-    ap.add_argument("--path", default="auto", choices=["auto", "direct", "fft"],
+    ap.add_argument("--path", default="auto", choices=["auto", "direct", "fft", "mfma"],
                     help="experiments: pin the kernel family (the default is the library's own choice)")
     ap.add_argument("--pmc", action="store_true",
                     help="collect roofline.traffic live: two extra rocprofv3 --pmc passes of a short run (N=1 only)")
@@ -494,8 +494,11 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
     # rank 0 (result collection only; SURVEY 8e asks for throughput with and without it)
     with_gather = None
     if USE_DIST and wl.get("gather") is not None:
-        gsteps = max(1, min(args.steps, 5))
-        wl["gather"]()                      # communicator / buffers warm
+        gsteps = max(1, min(args.steps, 5)) if on_gpu else 1   # the gloo rehearsal moves GBs through host sockets
+        if rank == 0:
+            print("bench.py: timing %d step(s) with the gather of every rank's outputs" % gsteps, file=sys.stderr, flush=True)
+        if on_gpu:
+            wl["gather"]()                  # communicator / buffers warm
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()

@@ -58,7 +58,7 @@ const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);
 
 // kernel families a handle can be pinned to (internal; the public create chooses by tap count)
-enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1 };
+enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1, SDR_PATH_MFMA = 2 };
 
 // direct-form plan of a tap vector (sdr_capi.hip: plan_direct)
 struct DirectPlan {
@@ -69,6 +69,24 @@ struct DirectPlan {
 };
 int plan_direct(const float* taps, size_t ntaps, int sample_kind, DirectPlan* p);
 void plan_direct_fill(const float* taps, const DirectPlan& p, float* g);
+
+// matrix-core direct form (fir_mfma.hip)
+struct MfmaArgs {
+    const float* in;
+    float* out;
+    const float* hist;   // [channels][hist_len]
+    const float* atab;   // smax x 64: the taps operand of every step, per lane
+    long long n;         // samples per channel
+    long long in_stride;
+    long long out_stride;
+    int hist_len;        // >= 4 (smax - 4) * stride, multiple of 4
+    int vec_in, vec_out; // 16-byte aligned input + history / output
+};
+int mfma_steps_for(size_t dense_taps);                 // 0: too many taps for this kernel
+size_t mfma_hist_samples(int smax, int stride);
+void mfma_fill_atab(const float* g, size_t ntaps, int smax, float* atab);
+hipError_t launch_fir_mfma(const MfmaArgs& a, bool real, int stride, int smax, size_t channels, hipStream_t stream);
+const char* fir_mfma_kernel_name(bool real, int stride);
 
 const KernelInfo* find_kernel(int R, int stride, bool real);
 size_t kernel_lds_bytes(const KernelInfo& k, int nchunks);

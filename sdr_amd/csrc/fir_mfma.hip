@@ -1,0 +1,220 @@
+// fir_mfma.hip -- direct-form FIR on the matrix cores: the Toeplitz-GEMM formulation that
+// BASELINE.json's north_star names, in exact fp32 (v_mfma_f32_16x16x4_f32: a k-ordered chain of
+// fp32 fused multiply-adds, no reduced-precision split).
+//
+//   y[n] = sum_t g[t] x[n - t]   (g: Tg dense real taps, x: one real "plane")
+//
+// is evaluated 256 outputs at a time as D = A * B with
+//   D[i][j] = y[ob + 16 j + i]                      16 x 16 outputs (one accumulator, 4 VGPRs)
+//   A[i][u] = g[i + HB - u]  (0 outside the taps)    16 x K Toeplitz matrix of the taps, K = HB + 16
+//   B[u][j] = x[ob + 16 j + u - HB]                  K x 16 Hankel matrix of the samples
+// in K/4 steps of the 16x16x4 instruction.  The A operand of step s is one VGPR per lane, the same
+// for every tile (loaded once per wave from a table the host builds); the B operand of step s is
+// one ds_read_b32 per lane from the staged samples (LDS row stride 18 floats per 16 samples: the
+// 64 lanes of a read then hit 64 different banks).  Useful share of the multiply-adds:
+// Tg / (HB + 16) = 0.80 at 64 taps.
+//
+// Planes: a real-tap filter acts on every interleaved component separately, so P planes are the
+// re / im parts of complex samples (P = 2), and the even / odd samples of a stream whose filter
+// has every other tap zero -- the Hilbert transformer, reference include/sdr/hilbert.hpp:46-55 --
+// (x2): its 127-tap design is two dense 64-tap half-rate filters.  P = W * stride in {1, 2, 4}.
+//
+// One workgroup (256 lanes) = one tile of 4096 floats (all planes), not persistent; each wave owns
+// four accumulators (1024 outputs).  fp32 MFMA and packed-fp32 VALU have the same peak, so this
+// kernel can only win where it holds the memory floor of small non-persistent tiles (5.7-6.0 TB/s)
+// while the overlap-save kernel sits at 5.2: profiles/r02_direct_vs_fft_vs_mfma.txt decides.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fir_kernels.h"
+
+namespace sdr_amd {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// virtual stream: history | input | zeros (the same contract as fir_direct's staging)
+template <int W>
+struct MStream {
+    const float* in;
+    const float* hist;
+    long long n;
+    int hist_len;
+    bool vec_ok;
+    __device__ __forceinline__ float elem(long long m, int k) const {
+        if (m < 0) {
+            const long long h = hist_len + m;
+            return h >= 0 ? hist[h * W + k] : 0.0f;
+        }
+        return m < n ? in[m * W + k] : 0.0f;
+    }
+    // 4 consecutive floats starting at float index f (f % 4 == 0) of the virtual stream
+    __device__ __forceinline__ f4 load4(long long f) const {
+        constexpr int NS = 4 / W;
+        const long long m = f / W; // exact: f is a multiple of 4
+        if (vec_ok) {
+            if (m >= 0 && m + NS <= n) return __builtin_nontemporal_load(reinterpret_cast<const f4*>(in + f));
+            if (m + NS <= 0 && m >= -(long long)hist_len && ((hist_len * W) & 3) == 0)
+                return *reinterpret_cast<const f4*>(hist + (long long)hist_len * W + f);
+        }
+        f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = elem(m + e / W, e % W);
+        return v;
+    }
+};
+
+} // namespace
+
+template <int P, int W, int SMAX>
+__global__ __launch_bounds__(256) void fir_mfma(MfmaArgs a) {
+    constexpr int HB = 4 * (SMAX - 4);   // history samples per plane ahead of a tile (>= taps - 1)
+    constexpr int OT = 4096 / P;         // outputs per plane per tile
+    constexpr int G = OT / 1024;         // 256-output column groups per wave per plane
+    constexpr int NIDX = OT + HB;        // staged samples per plane
+    constexpr int PS = NIDX + 2 * (NIDX / 16) + 2; // floats per plane in LDS (row stride 18 per 16 samples)
+    constexpr int NC = (4096 + P * HB) / 4; // 16-byte chunks to stage
+    extern __shared__ __align__(16) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long ch = blockIdx.y;
+    const long long tile = blockIdx.x;
+
+    MStream<W> src;
+    src.in = a.in + ch * a.in_stride * W;
+    src.hist = a.hist + ch * (long long)a.hist_len * W;
+    src.n = a.n;
+    src.hist_len = a.hist_len;
+    src.vec_ok = a.vec_in;
+
+    // ---- stage the tile and its left halo, de-interleaving the planes ---------------------
+    const long long F0 = (long long)P * (tile * OT - HB); // first float of the staged range (stream float index)
+    constexpr int ROUNDS = (NC + 255) / 256;
+    f4 st[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int ci = tid + 256 * r;
+        if (ci < NC) st[r] = src.load4(F0 + 4LL * ci);
+    }
+    // taps operand: one VGPR per step, the same for every tile
+    float A[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) A[s] = a.atab[s * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int ci = tid + 256 * r;
+        if (ci < NC) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fi = 4 * ci + e;
+                const int p = fi % P, idx = fi / P;
+                lds[p * PS + idx + 2 * (idx >> 4)] = st[r][e];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4 accumulators per wave: chain c = (column group gq, plane p) ----------------------
+    f4 acc[4];
+    const float* bptr[4];
+    const int j = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        acc[c] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int gq = c / P, p = c % P;
+        const int base = (w * G + gq) * 256; // plane-sample offset of the group inside the tile (multiple of 16)
+        bptr[c] = lds + p * PS + base + 2 * (base >> 4) + 18 * j + kk;
+    }
+    static_assert(G * P == 4, "four chains per wave");
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float b = bptr[c][4 * s + 2 * (s >> 2)];
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], b, acc[c], 0, 0, 0);
+        }
+    }
+
+    // ---- stores: lane holds outputs 16 j + 4 kk + r (r = 0..3) of every chain ----------------
+    float* out = a.out + ch * a.out_stride * W;
+    const long long nfl = a.n * W; // floats per channel
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        const long long ps = tile * OT + (w * G + gq) * 256 + 16 * j + 4 * kk; // first plane-sample of this lane
+        const long long f0 = ps * P;                                            // its float index in the stream
+        // P * 4 consecutive floats: float P*r + p = acc[gq*P + p][r]
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            f4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fl = 4 * q + e;
+                v[e] = acc[gq * P + fl % P][fl / P];
+            }
+            const long long f = f0 + 4 * q;
+            if (a.vec_out && f + 4 <= nfl) {
+                __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + f));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (f + e < nfl) out[f + e] = v[e];
+            }
+        }
+    }
+}
+
+// ---- launch table ----------------------------------------------------------------------------
+int mfma_steps_for(size_t dense_taps) {
+    for (int smax : {12, 20, 28, 36})
+        if (dense_taps <= (size_t)(4 * smax - 15)) return smax;
+    return 0;
+}
+
+size_t mfma_hist_samples(int smax, int stride) { return (size_t)4 * (smax - 4) * stride; }
+
+// atab[s * 64 + lane] = g[(lane & 15) + HB - (4 s + (lane >> 4))], zero outside [0, ntaps)
+void mfma_fill_atab(const float* g, size_t ntaps, int smax, float* atab) {
+    const int HB = 4 * (smax - 4);
+    for (int s = 0; s < smax; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int t = (lane & 15) + HB - (4 * s + (lane >> 4));
+            atab[s * 64 + lane] = (t >= 0 && (size_t)t < ntaps) ? g[t] : 0.0f;
+        }
+}
+
+template <int P, int W>
+static hipError_t launch_pw(const MfmaArgs& a, int smax, dim3 grid, hipStream_t stream) {
+    const int HB = 4 * (smax - 4), NIDX = 4096 / P + HB;
+    const size_t lds = (size_t)P * (NIDX + 2 * (NIDX / 16) + 2) * sizeof(float);
+    switch (smax) {
+        case 12: hipLaunchKernelGGL((fir_mfma<P, W, 12>), grid, dim3(256), lds, stream, a); break;
+        case 20: hipLaunchKernelGGL((fir_mfma<P, W, 20>), grid, dim3(256), lds, stream, a); break;
+        case 28: hipLaunchKernelGGL((fir_mfma<P, W, 28>), grid, dim3(256), lds, stream, a); break;
+        case 36: hipLaunchKernelGGL((fir_mfma<P, W, 36>), grid, dim3(256), lds, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_mfma(const MfmaArgs& a, bool real, int stride, int smax, size_t channels, hipStream_t stream) {
+    if (a.n == 0 || channels == 0) return hipSuccess;
+    const int W = real ? 1 : 2;
+    const long long nfl = a.n * W;
+    const long long tiles = (nfl + 4095) / 4096;
+    if (tiles > 0x7fffffffLL || channels > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)tiles, (unsigned)channels, 1);
+    if (real && stride == 1) return launch_pw<1, 1>(a, smax, grid, stream);
+    if (real && stride == 2) return launch_pw<2, 1>(a, smax, grid, stream);
+    if (!real && stride == 1) return launch_pw<2, 2>(a, smax, grid, stream);
+    if (!real && stride == 2) return launch_pw<4, 2>(a, smax, grid, stream);
+    return hipErrorInvalidValue;
+}
+
+const char* fir_mfma_kernel_name(bool real, int stride) {
+    if (real) return stride == 2 ? "fir_mfma<REAL,STRIDE=2>" : "fir_mfma<REAL>";
+    return stride == 2 ? "fir_mfma<COMPLEX,STRIDE=2>" : "fir_mfma<COMPLEX>";
+}
+
+} // namespace sdr_amd

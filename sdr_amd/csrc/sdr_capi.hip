@@ -54,6 +54,9 @@ struct sdr_fir {
     int hist_len = 0;
     int shift = 0;
     float* d_taps = nullptr;
+    bool use_mfma = false;  // matrix-core direct form (fir_mfma.hip)
+    int mfma_smax = 0;
+    float* d_atab = nullptr;
     bool use_fft = false;   // overlap-save FFT kernel instead of the direct form
     int fft_halo = 0;
     int fft_parts = 1;
@@ -149,7 +152,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
         return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
     if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
-    if (path < SDR_PATH_AUTO || path > SDR_PATH_FFT) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
+    if (path < SDR_PATH_AUTO || path > SDR_PATH_MFMA) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -177,7 +180,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
 #ifdef SDR_AMD_DIAG
     if (const char* ev = getenv("SDR_AMD_FFT")) use_fft = atoi(ev) != 0 && fft_parts <= 64;
 #endif
-    if (path != SDR_PATH_AUTO) use_fft = path != SDR_PATH_DIRECT && fft_parts <= 64;
+    if (path != SDR_PATH_AUTO) use_fft = path == SDR_PATH_FFT && fft_parts <= 64;
 
     sdr_fir* f = new (std::nothrow) sdr_fir();
     if (!f) return fail(SDR_ERR_NOMEM, "sdr_fir_create: out of memory");
@@ -191,6 +194,18 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     f->shift = shift;
     f->hist_len = plan.hist_len;
     f->use_fft = use_fft;
+    // matrix-core direct form: dense (or every-other-tap) filters of up to 129 kept taps
+    const int mfma_smax = (shift == 0) ? mfma_steps_for(plan.kept) : 0;
+    const bool use_mfma = !use_fft && path == SDR_PATH_MFMA;
+    if (use_mfma && mfma_smax == 0) {
+        delete f;
+        return fail(SDR_ERR_INVALID, "sdr_fir_create: no matrix-core kernel for this filter (more than 129 kept taps, or odd-phase taps)");
+    }
+    if (use_mfma) {
+        f->use_mfma = true;
+        f->mfma_smax = mfma_smax;
+        f->hist_len = std::max<int>(f->hist_len, (int)mfma_hist_samples(mfma_smax, stride) + 4);
+    }
     if (use_fft) {
         f->fft_halo = fft_halo;
         f->fft_parts = fft_parts;
@@ -215,6 +230,13 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if ((e = hipMalloc(&f->d_hist[1], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
     if ((e = hipMemcpy(f->d_taps, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(taps)");
+    if (use_mfma) {
+        std::vector<float> at((size_t)mfma_smax * 64);
+        mfma_fill_atab(g.data(), plan.kept, mfma_smax, at.data());
+        if ((e = hipMalloc(&f->d_atab, at.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(taps operand)");
+        if ((e = hipMemcpy(f->d_atab, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+            return bail(e, "hipMemcpy(taps operand)");
+    }
     if (use_fft) {
         // Filter spectrum H[k] = (1/N) sum_j h[j] exp(-2 pi i j k / N), N = 4096, in
         // double on the host, stored in the order the kernel's lanes consume it.
@@ -299,6 +321,7 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (f->d_taps) (void)hipFree(f->d_taps);
+    if (f->d_atab) (void)hipFree(f->d_atab);
     if (f->d_hperm) (void)hipFree(f->d_hperm);
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
@@ -343,6 +366,27 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         f->cur ^= 1;
         return SDR_OK;
     }
+    const bool multi = f->channels > 1;
+    const int vec_in = ((uintptr_t)d_in % 16 == 0) && (!multi || (in_stride * f->w) % 4 == 0);
+    const int vec_out = ((uintptr_t)d_out % 16 == 0) && (!multi || (out_stride * f->w) % 4 == 0);
+    if (f->use_mfma) {
+        MfmaArgs m;
+        m.in = d_in;
+        m.out = d_out;
+        m.hist = f->d_hist[f->cur];
+        m.atab = f->d_atab;
+        m.n = (long long)n;
+        m.in_stride = (long long)in_stride;
+        m.out_stride = (long long)out_stride;
+        m.hist_len = f->hist_len;
+        m.vec_in = vec_in;
+        m.vec_out = vec_out;
+        SDR_HIP(launch_fir_mfma(m, f->kind == SDR_REAL, f->k->stride, f->mfma_smax, f->channels, stream));
+        SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
+                                     f->hist_len, f->w, f->channels, stream));
+        f->cur ^= 1;
+        return SDR_OK;
+    }
     FirArgs a;
     a.in = d_in;
     a.out = d_out;
@@ -354,9 +398,8 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
     a.nchunks = f->nchunks;
     a.hist_len = f->hist_len;
     a.shift = f->shift;
-    const bool multi = f->channels > 1;
-    a.vec_in = ((uintptr_t)d_in % 16 == 0) && (!multi || (in_stride * f->w) % 4 == 0);
-    a.vec_out = ((uintptr_t)d_out % 16 == 0) && (!multi || (out_stride * f->w) % 4 == 0);
+    a.vec_in = vec_in;
+    a.vec_out = vec_out;
     SDR_HIP(launch_fir(*f->k, a, f->channels, stream));
     SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
                                  f->hist_len, f->w, f->channels, stream));
@@ -449,6 +492,7 @@ extern "C" size_t sdr_fir_ntaps(const sdr_fir_t* f) { return f ? f->ntaps : 0; }
 extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? (f->use_fft ? 1 : f->k->stride) : 0; }
 extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) {
     if (!f) return "";
+    if (f->use_mfma) return fir_mfma_kernel_name(f->kind == SDR_REAL, f->k->stride);
     return f->use_fft ? fir_fft_kernel_name(f->kind == SDR_REAL) : f->k->name;
 }
 

@@ -83,6 +83,8 @@ def gather_chunks(y, dist, dst=0):
     elsewhere.  Compute never waits on this: it is result collection only."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
+    if y.is_cuda and dist.get_backend() != "nccl":
+        y = y.cpu()   # the CPU rehearsal backend (gloo) gathers host tensors
     n = torch.tensor([y.shape[0]], dtype=torch.int64, device=y.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
