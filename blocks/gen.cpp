@@ -8,11 +8,9 @@
 //
 // Runs until its output closes (SIGPIPE), like the reference; with unit=stream (FREQ =
 // the stream id of a frequency-control input on stdin, blocks/gen.cpp:61-81, 143-146,
-// 167-176) it runs until that input ends, retuning at packet boundaries.  Samples are
-// produced a few packets per GPU round trip, so a retune takes effect within that many
-// packets (the reference: within one).
+// 167-176) it runs until that input ends, looking at the control input before every packet
+// it produces, like the reference (one packet per GPU round trip in this mode).
 #include <algorithm>
-#include <atomic>
 #include <condition_variable>
 #include <cmath>
 #include <cstdlib>
@@ -44,31 +42,46 @@ float cycles_per_sample(int unit, float f, uint64_t sample_rate) {
     return f;
 }
 
-// blocks/gen.cpp:61-81: the control input's Frequency / Wavelength / SampleCount packets
-// of stream `id`, first float of the payload, published for the generator loop
-std::atomic<float> freq_msg(0.0f);
-std::atomic<bool> source_end(false);
-std::atomic<bool> freq_msg_set(false);
-
-void freq_input(uint16_t id, uint64_t sample_rate) {
-    host::PacketReader source(0);
-    while (source.next()) {
-        const host::PacketHeader& h = source.header();
-        int unit = 3;
-        if (h.content == host::kFrequency) unit = 0;
-        else if (h.content == host::kWavelength) unit = 1;
-        else if (h.content == host::kSampleCount) unit = 2;
-        if (h.id == id && unit != 3 && h.size % sizeof(float) == 0 && h.size >= sizeof(float)) {
+// The frequency-control input of unit=stream (reference blocks/gen.cpp:61-81, 143-146): a reader
+// thread takes Frequency / Wavelength / SampleCount packets of stream `id` from stdin (first
+// float of the payload) and leaves the latest value, or the end of the input, for the generator
+// loop, which looks before every packet it produces (:167-176, :187).
+class FrequencyControl {
+public:
+    // Reader side: runs until stdin ends.
+    void read_stdin(uint16_t id, uint64_t sample_rate) {
+        host::PacketReader source(0);
+        while (source.next()) {
+            const host::PacketHeader& h = source.header();
+            const int unit = h.content == host::kFrequency ? 0 : h.content == host::kWavelength ? 1
+                             : h.content == host::kSampleCount ? 2 : 3;
+            if (h.id != id || unit == 3 || h.size < sizeof(float) || h.size % sizeof(float) != 0) continue;
             float f = 0.0f;
-            if (source.read_payload(&f, sizeof f) == sizeof f) {
-                freq_msg.store(cycles_per_sample(unit, f, sample_rate), std::memory_order_relaxed);
-                freq_msg_set.store(true, std::memory_order_release);
-            }
+            if (source.read_payload(&f, sizeof f) != sizeof f) continue;
+            std::lock_guard<std::mutex> lk(mu_);
+            value_ = cycles_per_sample(unit, f, sample_rate);
+            news_ = true;
         }
+        std::lock_guard<std::mutex> lk(mu_);
+        ended_ = news_ = true;
     }
-    source_end.store(true, std::memory_order_relaxed);
-    freq_msg_set.store(true, std::memory_order_release);
-}
+    // Generator side: anything new since the last look?  *ended: the input is over (the reference
+    // stops at the first look after the end, whatever value arrived just before it).
+    bool poll(float* cps, bool* ended) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!news_) return false;
+        news_ = false;
+        *cps = value_;
+        *ended = ended_;
+        return true;
+    }
+
+private:
+    std::mutex mu_;
+    float value_ = 0.0f;
+    bool news_ = false, ended_ = false;
+};
+FrequencyControl control;
 } // namespace
 
 int main(int argc, char* argv[]) {
@@ -136,12 +149,14 @@ int main(int argc, char* argv[]) {
         return -1;
     }
     if (!no_source) {                                                         // :143-146
-        std::thread thr(freq_input, static_cast<uint16_t>(freq.as_float()), rate);
+        std::thread thr([&, rate] { control.read_stdin(static_cast<uint16_t>(freq.as_float()), rate); });
         thr.detach();
     }
     host::widen_pipe(1);
     float current = cps;
-    size_t blocks_per_call = no_source ? 512 : 4; // ~4 MiB per round trip; short when retunable
+    // ~4 MiB per GPU round trip with a fixed frequency; ONE packet per round trip with a control
+    // input, so that a retune takes effect at the next packet produced, as in the reference
+    size_t blocks_per_call = no_source ? 512 : 1;
     if (const char* e = std::getenv("SDR_AMD_GEN_BLOCKS")) blocks_per_call = std::max(1, std::atoi(e));
     // two pinned buffers: with a fixed frequency a producer thread fills one on the GPU while
     // the main thread writes the other to the pipe
@@ -210,9 +225,10 @@ int main(int argc, char* argv[]) {
         producer.join();
     } else {
         for (;;) {
-            if (freq_msg_set.exchange(false, std::memory_order_acq_rel)) {                        // :167-176
-                if (source_end.load(std::memory_order_relaxed)) break;
-                const float msg = freq_msg.load(std::memory_order_relaxed);
+            float msg = current;
+            bool ended = false;
+            if (control.poll(&msg, &ended)) {                                                      // :167-176
+                if (ended) break;
                 if (msg != current) {
                     current = msg;
                     sdr_gen_set_frequency(g, current);

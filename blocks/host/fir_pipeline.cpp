@@ -22,12 +22,23 @@ FirPipeline::FirPipeline(const PipelineConfig& cfg) : cfg_(cfg), skip_left_(cfg.
 }
 
 FirPipeline::~FirPipeline() {
+    // order matters: the writer thread reads the batches, and an asynchronous device-to-host copy
+    // of an unfinished batch may still target b.out -- end the thread, let sdr_fir_destroy
+    // synchronise the handles' streams, and only then free the pinned batches
+    if (writer_.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            done_ = true;
+        }
+        cv_.notify_all();
+        writer_.join();
+    }
+    sdr_fir_destroy(fir_[0]);
+    sdr_fir_destroy(fir_[1]);
     for (auto& b : pool_) {
         sdr_host_free(b.in);
         sdr_host_free(b.out);
     }
-    sdr_fir_destroy(fir_[0]);
-    sdr_fir_destroy(fir_[1]);
 }
 
 // A packet larger than the batch size gets a batch of its own, grown to fit (the wire
@@ -302,6 +313,15 @@ int FirPipeline::run(int in_fd, int out_fd) {
     }
     if (!rc) rc = flush(true);
     if (inflight && !rc) rc = finish(inflight);
+    if (rc) {
+        // error exit with a batch possibly still queued on the GPU: wait for both staging slots
+        // before anything that owns their buffers goes away (errors here change nothing)
+        for (sdr_fir_t* f : fir_)
+            if (f) {
+                (void)sdr_fir_wait(f, 0);
+                (void)sdr_fir_wait(f, 1);
+            }
+    }
     {
         std::lock_guard<std::mutex> lk(mu_);
         done_ = true;

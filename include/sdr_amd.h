@@ -163,9 +163,11 @@ int sdr_chain_reset(sdr_chain_t* c);
  * elsewhere, so this handle is not at the start of the stream -- no group-delay skip
  * and no warm-up are applied from here on.  Histories are zeroed: feed at least
  * sdr_chain_ntaps()-1 samples preceding the first output you keep (their outputs are
- * to be discarded).  position must lie beyond the start-of-stream region
- * (>= sum of stage tap counts); 0 is the same as sdr_chain_reset. */
+ * to be discarded).  position must be 0 (the same as sdr_chain_reset) or at least
+ * sdr_chain_min_seek(c): beyond the start-of-stream region -- max(staged warm-up prefix,
+ * total group-delay skip) -- plus sdr_chain_ntaps(c). */
 int sdr_chain_seek(sdr_chain_t* c, size_t position);
+size_t sdr_chain_min_seek(const sdr_chain_t* c);
 void sdr_chain_destroy(sdr_chain_t* c);
 /* Taps of the single equivalent filter (for tests). */
 size_t sdr_chain_ntaps(const sdr_chain_t* c);

@@ -58,6 +58,8 @@ def lib():
         L.sdr_chain_process_device.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz), vp]
         L.sdr_chain_reset.argtypes = [vp]
         L.sdr_chain_seek.argtypes = [vp, sz]
+        L.sdr_chain_min_seek.argtypes = [vp]
+        L.sdr_chain_min_seek.restype = sz
         L.sdr_gen_advance.argtypes = [vp, sz]
         L.sdr_gen_set_hilbert.argtypes = [vp, sz, C.c_int]
         L.sdr_chain_destroy.argtypes = [vp]
@@ -313,6 +315,11 @@ class Chain:
 
     def reset(self):
         _check(lib().sdr_chain_reset(self._h))
+
+    @property
+    def min_seek(self):
+        """Smallest non-zero position seek() accepts (end of the start-of-stream region)."""
+        return lib().sdr_chain_min_seek(self._h)
 
     def seek(self, position):
         """Not at the start of the stream: `position` inputs were consumed elsewhere."""

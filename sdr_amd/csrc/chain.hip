@@ -37,6 +37,7 @@ struct sdr_chain {
     size_t prefix = 0;     // P = M0 + D inputs go through the staged path too
     size_t pos = 0;        // inputs consumed so far
     size_t emitted = 0;    // outputs produced so far
+    bool dirty = false;    // the fused filter has taken samples since the last reset / seek
     float* scratch[3] = {nullptr, nullptr, nullptr}; // [channels][prefix] each
     float* warm_in = nullptr; // sdr_chain_generate_device: the generated packets that cover the warm-up prefix
     size_t warm_cap = 0;      // floats
@@ -99,15 +100,14 @@ extern "C" int sdr_chain_create(sdr_chain_t** out, size_t nstages, const float* 
         }
     }
     if (rc == SDR_OK) {
-        int prev = 0;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(device);
+        sdr_amd::DeviceGuard guard(device);
+        if (guard.err != hipSuccess) rc = hipfail(guard.err, "hipSetDevice");
         const size_t bytes = std::max<size_t>(c->prefix + c->total_skip, 1) * channels * c->w * sizeof(float);
         for (float*& p : c->scratch) {
+            if (rc != SDR_OK) break;
             hipError_t e = hipMalloc(&p, bytes);
-            if (e != hipSuccess) { rc = hipfail(e, "hipMalloc(chain scratch)"); break; }
+            if (e != hipSuccess) rc = hipfail(e, "hipMalloc(chain scratch)");
         }
-        (void)hipSetDevice(prev);
     }
     if (rc != SDR_OK) {
         std::string keep = sdr_last_error();
@@ -127,18 +127,25 @@ extern "C" int sdr_chain_reset(sdr_chain_t* c) {
         if (rc == SDR_OK) rc = sdr_fir_reset(f);
     c->skip_left = c->skips;
     c->pos = c->emitted = 0;
+    c->dirty = false;
     return rc;
+}
+
+// Smallest position sdr_chain_seek accepts (besides 0): past the start-of-stream region -- the
+// staged warm-up prefix or the swallowed outputs, whichever is longer -- plus one filter length.
+extern "C" size_t sdr_chain_min_seek(const sdr_chain_t* c) {
+    if (!c) return 0;
+    return std::max(c->prefix, c->total_skip) + c->fused_ntaps;
 }
 
 extern "C" int sdr_chain_seek(sdr_chain_t* c, size_t position) {
     if (!c) return fail(SDR_ERR_INVALID, "sdr_chain_seek: NULL handle");
     if (position == 0) return sdr_chain_reset(c);
-    size_t lead = std::max(c->prefix, c->total_skip);
-    if (position < lead + c->fused_ntaps)
-        return fail(SDR_ERR_INVALID, "sdr_chain_seek: position lies inside the start-of-stream region");
+    if (position < sdr_chain_min_seek(c))
+        return fail(SDR_ERR_INVALID, "sdr_chain_seek: position lies inside the start-of-stream region (see sdr_chain_min_seek)");
     int rc = sdr_chain_reset(c);
     if (rc != SDR_OK) return rc;
-    for (size_t& s : c->skip_left) s = 0;
+    for (size_t& s : c->skip_left) s = 0;   // (sdr_chain_reset above zeroed the histories: dirty = false)
     c->pos = position;
     c->emitted = position - c->total_skip;
     return SDR_OK;
@@ -151,6 +158,10 @@ extern "C" int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t
     if (n == 0) return SDR_OK;
     if (!d_in || !d_out) return fail(SDR_ERR_INVALID, "sdr_chain_process_device: NULL buffer");
     hipStream_t stream = (hipStream_t)hip_stream;
+    // every copy and launch below belongs to the chain's device, whatever device is current
+    sdr_amd::DeviceGuard guard(c->device);
+    if (guard.err != hipSuccess) return hipfail(guard.err, "hipSetDevice");
+    c->dirty = true;
     const size_t w = c->w, fw = w * sizeof(float);
     const float* in = (const float*)d_in;
     float* out = (float*)d_out;
@@ -207,10 +218,14 @@ extern "C" int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t bl
     if (!c || !g) return fail(SDR_ERR_INVALID, "sdr_chain_generate_device: NULL handle");
     // The generator is fused into the overlap-save kernels only.  A chain whose fused filter is
     // short enough for the direct form is moved over before its first sample (allocates once).
+    sdr_amd::DeviceGuard guard(c->device);
+    if (guard.err != hipSuccess) return hipfail(guard.err, "hipSetDevice");
     if (!sdr_amd::fir_uses_overlap_save(c->fused) && c->kind == SDR_REAL && c->channels == 1) {
-        if (c->pos != 0)
+        // moving the filter is safe while its history is still zero: at the start of the stream,
+        // after a reset, and after a seek (which zeroes the histories)
+        if (c->dirty)
             return fail(SDR_ERR_INVALID, "sdr_chain_generate_device: this short chain has already filtered samples through the "
-                                         "direct-form kernel; generate from the start of the stream (or after sdr_chain_reset)");
+                                         "direct-form kernel; generate right after create, sdr_chain_reset or sdr_chain_seek");
         sdr_fir_t* f = nullptr;
         int rc0 = sdr_amd::fir_create_overlap_save(&f, c->fused_taps.data(), c->fused_taps.size(), c->kind, c->channels, c->device);
         if (rc0 != SDR_OK) return rc0;
@@ -232,14 +247,10 @@ extern "C" int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t bl
     if (c->pos < lead) {
         const size_t k = std::min(blocks, (lead - c->pos + B - 1) / B);
         if (k * B > c->warm_cap) {
-            int prev = 0;
-            (void)hipGetDevice(&prev);
-            (void)hipSetDevice(c->device);
             if (c->warm_in) (void)hipFree(c->warm_in);
             c->warm_in = nullptr;
             c->warm_cap = 0;
             hipError_t e = hipMalloc(&c->warm_in, k * B * sizeof(float));
-            (void)hipSetDevice(prev);
             if (e != hipSuccess) return hipfail(e, "hipMalloc(chain warm-up input)");
             c->warm_cap = k * B;
         }
@@ -254,6 +265,7 @@ extern "C" int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t bl
     if (blocks) {
         rc = sdr_amd::fir_process_generated(c->fused, g, blocks, out + done, stream);
         if (rc != SDR_OK) return rc;
+        c->dirty = true;
         c->pos += blocks * B;
         c->emitted += blocks * B;
         done += blocks * B;

@@ -67,8 +67,12 @@ struct MStream {
 
 } // namespace
 
+// waves per SIMD asked of the register allocator: 8 workgroups per CU fit the LDS (18 KB each);
+// the taps operand (SMAX registers) sets what the register file allows
+constexpr int mfma_waves(int smax) { return smax <= 20 ? 8 : smax <= 28 ? 6 : 5; }
+
 template <int P, int W, int SMAX>
-__global__ __launch_bounds__(256) void fir_mfma(MfmaArgs a) {
+__global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
     constexpr int HB = 4 * (SMAX - 4);   // history samples per plane ahead of a tile (>= taps - 1)
     constexpr int OT = 4096 / P;         // outputs per plane per tile
     constexpr int G = OT / 1024;         // 256-output column groups per wave per plane
@@ -137,37 +141,44 @@ __global__ __launch_bounds__(256) void fir_mfma(MfmaArgs a) {
         }
     }
 
-    // ---- stores: lane holds outputs 16 j + 4 kk + r (r = 0..3) of every chain ----------------
+    // ---- stores.  A lane holds outputs 16 j + 4 kk + r (r = 0..3) of every chain, i.e. with P
+    // planes 4 floats out of every 4 P of the stream: stored from the registers, an instruction
+    // would fill only 1/P of every cache line it touches.  The accumulators go back through LDS in
+    // stream order instead (each wave's 1024 floats are contiguous: a wave-private region once
+    // every wave has finished reading the staged samples), and come out as 16 contiguous bytes
+    // per lane, 1 KiB per instruction.  Row padding: 4 floats per 64 (keeps 16-byte alignment).
+    __syncthreads();
+    static_assert(P * PS >= 4096 + 4 * 64, "the staged planes are large enough to hold the tile's outputs");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int gq = c / P, p = c % P;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = P * ((w * G + gq) * 256 + 16 * j + 4 * kk + r) + p; // float index inside the tile
+            lds[f + 4 * (f >> 6)] = acc[c][r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
     float* out = a.out + ch * a.out_stride * W;
     const long long nfl = a.n * W; // floats per channel
 #pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-        const long long ps = tile * OT + (w * G + gq) * 256 + 16 * j + 4 * kk; // first plane-sample of this lane
-        const long long f0 = ps * P;                                            // its float index in the stream
-        // P * 4 consecutive floats: float P*r + p = acc[gq*P + p][r]
+    for (int q = 0; q < 4; ++q) {
+        const int fi = 1024 * w + 256 * q + 4 * lane;
+        const f4 v = *reinterpret_cast<const f4*>(&lds[fi + 4 * (fi >> 6)]);
+        const long long f = tile * 4096 + fi;
+        if (a.vec_out && f + 4 <= nfl) {
+            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + f));
+        } else {
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            f4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int fl = 4 * q + e;
-                v[e] = acc[gq * P + fl % P][fl / P];
-            }
-            const long long f = f0 + 4 * q;
-            if (a.vec_out && f + 4 <= nfl) {
-                __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + f));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (f + e < nfl) out[f + e] = v[e];
-            }
+            for (int e = 0; e < 4; ++e)
+                if (f + e < nfl) out[f + e] = v[e];
         }
     }
 }
 
 // ---- launch table ----------------------------------------------------------------------------
 int mfma_steps_for(size_t dense_taps) {
-    for (int smax : {12, 20, 28, 36})
+    for (int smax : {8, 12, 16, 20, 24, 28, 32, 36})
         if (dense_taps <= (size_t)(4 * smax - 15)) return smax;
     return 0;
 }
@@ -189,9 +200,13 @@ static hipError_t launch_pw(const MfmaArgs& a, int smax, dim3 grid, hipStream_t 
     const int HB = 4 * (smax - 4), NIDX = 4096 / P + HB;
     const size_t lds = (size_t)P * (NIDX + 2 * (NIDX / 16) + 2) * sizeof(float);
     switch (smax) {
+        case 8: hipLaunchKernelGGL((fir_mfma<P, W, 8>), grid, dim3(256), lds, stream, a); break;
         case 12: hipLaunchKernelGGL((fir_mfma<P, W, 12>), grid, dim3(256), lds, stream, a); break;
+        case 16: hipLaunchKernelGGL((fir_mfma<P, W, 16>), grid, dim3(256), lds, stream, a); break;
         case 20: hipLaunchKernelGGL((fir_mfma<P, W, 20>), grid, dim3(256), lds, stream, a); break;
+        case 24: hipLaunchKernelGGL((fir_mfma<P, W, 24>), grid, dim3(256), lds, stream, a); break;
         case 28: hipLaunchKernelGGL((fir_mfma<P, W, 28>), grid, dim3(256), lds, stream, a); break;
+        case 32: hipLaunchKernelGGL((fir_mfma<P, W, 32>), grid, dim3(256), lds, stream, a); break;
         case 36: hipLaunchKernelGGL((fir_mfma<P, W, 36>), grid, dim3(256), lds, stream, a); break;
         default: return hipErrorInvalidValue;
     }

@@ -58,7 +58,7 @@ def filter_chunk(make_state, source, n_total, ntaps, rank, world, align=1):
     return start, y
 
 
-def plan_generated_chain(n_blocks, world, block_size, chain_ntaps):
+def plan_generated_chain(n_blocks, world, block_size, chain_ntaps, min_seek=None):
     """BASELINE config 5: a generated stream of n_blocks packets of block_size samples
     through a fused chain of chain_ntaps combined taps, cut into whole packets.  Per
     rank: (first_block, blocks, halo_blocks) -- the rank positions its generator at
@@ -66,12 +66,15 @@ def plan_generated_chain(n_blocks, world, block_size, chain_ntaps):
     (Chain.seek; rank 0 starts the stream instead), discards the outputs of the
     halo_blocks priming packets and keeps the next blocks * block_size outputs.  The
     outputs of all ranks, in rank order, are the stream's outputs (rank 0's are
-    shorter by the chain's total group-delay skip)."""
+    shorter by the chain's total group-delay skip).  min_seek: Chain.min_seek of the chain
+    (sdr_chain_min_seek), the smallest position a rank may seek to; without it a safe
+    over-estimate (4 * chain_ntaps) is used."""
     halo = -(-(chain_ntaps - 1) // block_size)
+    floor = 4 * chain_ntaps if min_seek is None else int(min_seek)
     plan = []
     for first, cnt in plan_chunks(n_blocks, world, 1):
         h = 0 if first == 0 else halo
-        if first and (first - h) * block_size < 4 * chain_ntaps:
+        if first and (first - h) * block_size < floor:
             raise ValueError("chunks this small would start inside the start-of-stream region")
         plan.append((first, cnt, h))
     return plan

@@ -163,21 +163,30 @@ def test_gen_block_other_waveforms_match_reference_packets(golden_dir):
 
 
 def test_gen_block_frequency_control_input():
-    """unit=stream (blocks/gen.cpp:61-81, 167-176): Frequency packets of the named stream
+    """unit=stream (blocks/gen.cpp:61-81, 167-176, 187): Frequency packets of the named stream
     on stdin retune the generator at a packet boundary; the generator ends when the control
     input ends.  Every output packet must continue the phase recurrence with either the
-    old or the new frequency, old before new."""
+    old or the new frequency, old before new -- and, like the reference, the switch happens on
+    the FIRST packet generated after the control packet was read: the test lets the generator
+    block on a full output pipe, sends the control packet, waits, and then counts the
+    old-frequency packets that were already in the pipe (its capacity) plus the one blocked
+    in write()."""
+    import fcntl
     import time
     B, rate = 2044, 1000000
+    pkt = 16 + 4 * B
     proc = subprocess.Popen([os.path.join(BIN, "gen"), "7", "stream", "sine", "sample_rate=1M", "mode=real", "amp=0.5", "phi=90"],
                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     proc.stdin.write(O.pack_packet(3, 3, np.float32(5e4).tobytes(), 0))      # foreign stream id: ignored
     proc.stdin.write(O.pack_packet(7, 6, np.zeros(4, np.float32).tobytes(), 0))  # not a frequency packet: ignored
     proc.stdin.flush()
-    first = proc.stdout.read(8 * (16 + 4 * B))                                # cps = 0 until told otherwise
+    first = proc.stdout.read(8 * pkt)                                         # cps = 0 until told otherwise
+    time.sleep(1.0)                                                           # the generator fills the pipe and blocks
+    cap = fcntl.fcntl(proc.stdout.fileno(), 1032)                             # F_GETPIPE_SZ (the block widened it)
     proc.stdin.write(O.pack_packet(7, 3, np.float32(125e3).tobytes(), 0))     # Frequency, Hz
     proc.stdin.flush()
-    more = proc.stdout.read(64 * (16 + 4 * B))
+    time.sleep(1.0)                                                           # the control thread has read it by now
+    more = proc.stdout.read(cap + 64 * pkt)
     proc.stdin.close()                                                        # control input ends: gen ends
     t0 = time.time()
     rest = b""
@@ -191,16 +200,20 @@ def test_gen_block_frequency_control_input():
     pk = [p for p in pk if len(p[4]) == p[2]]
     assert len(pk) >= 72 and all(p[0] == 0 and p[1] == O.SIGNAL and p[2] == 4 * B for p in pk)
     f_new = float(np.float32(125e3) / np.float32(rate))
-    phi, cps, switched = float(np.float32(90.0) / np.float32(360.0)), 0.0, False
+    phi, cps, switched = float(np.float32(90.0) / np.float32(360.0)), 0.0, None
     for k, p in enumerate(pk):
         got = np.frombuffer(p[4], np.float32)
         ref, phi_next = O.gen_real(1, B, 0.5, cps, phi, 1)
-        if not switched and np.max(np.abs(got - ref)) > 1e-6:
-            cps, switched = f_new, True
+        if switched is None and np.max(np.abs(got - ref)) > 1e-6:
+            cps, switched = f_new, k
             ref, phi_next = O.gen_real(1, B, 0.5, cps, phi, 1)
         assert np.max(np.abs(got - ref)) <= 1e-6, k
         phi = phi_next
-    assert switched and k >= 8
+    assert switched is not None and k >= 8
+    # old-frequency packets after the 8 read up front: what the full pipe held, plus the packet
+    # that was blocked in write() (generated before the control packet arrived) -- not one more
+    in_pipe = -(-cap // pkt)
+    assert in_pipe <= switched - 8 <= in_pipe + 1, (switched, cap)
 
 
 def test_gen_pipe_hilbert_equals_reference_chain(golden_dir):
@@ -215,6 +228,32 @@ def test_gen_pipe_hilbert_equals_reference_chain(golden_dir):
     got = O.parse_packets(out)
     assert [p[:4] for p in got] == [p[:4] for p in ref]
     assert rel_err(samples(got), samples(ref)) <= TOL
+
+
+def test_config1_full_size_pipe():
+    """BASELINE configs[0] at its full size under the driver: `gen sine | head -c | hilbert` on
+    2^24 float32 samples through real unix pipes (8208 whole packets of 2044 samples and a
+    truncated 8209th), against the oracle's generator + hilbert block loop (C, a few seconds):
+    headers byte-exact, N_out = 2^24 - 63, samples within 1e-5 of the output RMS.  No reference
+    binary is needed here (profiles/r01_c1_pipe_2p24.json holds the run beside the reference's
+    own blocks)."""
+    n, B = 1 << 24, 2044
+    whole, rest = divmod(n, B)
+    nbytes = whole * (16 + 4 * B) + 16 + 4 * rest
+    cmd = "%s freq=100k waveform=sine sample_rate=1M mode=real | head -c %d | %s" % (
+        os.path.join(BIN, "gen"), nbytes, os.path.join(BIN, "hilbert"))
+    out = subprocess.run(cmd, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300).stdout
+    cps = float(np.float32(100e3) / np.float32(1e6))      # convert_freq, include/sdr/options.hpp:120-141
+    x, _ = O.gen_real(whole + 1, B, 1.0, cps, 0.0, 1)
+    dur = B * 1000000000 // 1000000
+    stream = b"".join(O.pack_packet(0, O.SIGNAL, x[k * B:(k + 1) * B].tobytes(), dur) for k in range(whole + 1))[:nbytes]
+    want = O.parse_packets(O.hilbert_block(stream))
+    got = O.parse_packets(out)
+    assert len(got) == len(want) == whole + 1
+    assert [p[:4] for p in got] == [p[:4] for p in want]
+    sg, sw = samples(got), samples(want)
+    assert len(sg) == len(sw) == n - 63
+    assert rel_err(sg, sw) <= TOL
 
 
 def test_stream_filter_fir_extension(golden_dir):

@@ -72,6 +72,38 @@ def test_both_kernel_families(path, kind, ntaps, cplx):
     assert rel_err(y, O.fir(taps, x)) <= TOL
 
 
+@pytest.mark.parametrize("kind,ntaps,cplx", [("lowpass", 127, True), ("lowpass", 127, False), ("hilbert", 127, False),
+                                             ("hilbert", 127, True), ("hilbert", 255, False), ("hilbert", 255, True),
+                                             ("lowpass", 65, True), ("lowpass", 49, False), ("lowpass", 33, True),
+                                             ("random", 16, False), ("random", 2, True), ("random", 1, False),
+                                             ("random", 97, True), ("random", 113, False), ("random", 129, True)])
+def test_matrix_core_kernels(kind, ntaps, cplx):
+    """fir_mfma (the Toeplitz form on the fp32 matrix cores): dense filters up to 129 taps and
+    every-other-tap (Hilbert) designs up to 257, real and complex, stream cut at tile-sized, tiny and
+    ragged places, two channels with a padded stride."""
+    rng = np.random.default_rng(ntaps + 5 * cplx)
+    taps = taps_for(kind, ntaps)
+    n = 33333
+    x = rand(rng, n, cplx)
+    st = sdr_amd.FirState(taps, cplx, path="mfma")
+    assert "mfma" in st.kernel_name, st.kernel_name
+    cuts = [0, 1, 4000, 4001, 12288, 20000, n]
+    y = np.concatenate([sdr_amd.fir(st, x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+    assert rel_err(y, O.fir(taps, x)) <= TOL
+    x2 = np.stack([rand(rng, 9001, cplx) for _ in range(2)])
+    st2 = sdr_amd.FirState(taps, cplx, channels=2, path="mfma")
+    y2 = np.concatenate([sdr_amd.fir(st2, x2[:, :5000]), sdr_amd.fir(st2, x2[:, 5000:])], axis=1)
+    for c in range(2):
+        assert rel_err(y2[c], O.fir(taps, x2[c])) <= TOL, c
+
+
+def test_matrix_core_kernel_refuses_what_it_cannot_do():
+    with pytest.raises(sdr_amd.SdrError):
+        sdr_amd.FirState(taps_for("lowpass", 255), True, path="mfma")     # 255 dense taps
+    with pytest.raises(sdr_amd.SdrError):
+        sdr_amd.FirState(taps_for("hilbert", 125), False, path="mfma")    # non-zero taps on the odd phase
+
+
 @pytest.mark.parametrize("ntaps", [2049, 2050, 4096, 9001])
 def test_partitioned_long_filters(ntaps):
     """More than 2049 taps: uniformly partitioned overlap-save (hop 2048)."""
