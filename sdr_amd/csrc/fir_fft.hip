@@ -354,27 +354,26 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         return a.in + (p.ch * a.in_stride + first_out(p) - HALO) * W;
     };
     // rows [LO, HI) of a tile's 16 rows of 256 points
+    // With the spectrum cache a workgroup walks consecutive hops of 2048 samples: rows 8..15 of
+    // this window are rows 0..7 of its next one.  Those are loaded with the default cache policy
+    // (they come back out of L2 one tile later); rows read for the last time stay non-temporal.
+    // (r01: every row non-temporal -> each input fetched from HBM twice, 1.93x the reads.)
+    auto row = [&](const float* p0, int n2) -> f2 {
+        const bool again = CACHE && n2 >= 8;
+        if (REAL) {
+            const float* q = p0 + 256 * n2;
+            return again ? f2{q[tid], q[D + tid]} : f2{stream_load(q + tid), stream_load(q + D + tid)};
+        }
+        const f2* q = reinterpret_cast<const f2*>(p0 + 512 * n2) + tid;
+        return again ? *q : stream_load(q);
+    };
     auto load_rows = [&](const float* p0, f2 (&dst)[16], auto lo, auto hi) {
 #pragma unroll
-        for (int n2 = decltype(lo)::value; n2 < decltype(hi)::value; ++n2) {
-            if (REAL) {
-                const float* q = p0 + 256 * n2;
-                dst[n2] = f2{stream_load(q + tid), stream_load(q + D + tid)};
-            } else {
-                dst[n2] = stream_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
-            }
-        }
+        for (int n2 = decltype(lo)::value; n2 < decltype(hi)::value; ++n2) dst[n2] = row(p0, n2);
     };
     auto load = [&](const float* p0, f2 (&dst)[16]) {
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
-            if (REAL) {
-                const float* q = p0 + 256 * n2;
-                dst[n2] = f2{stream_load(q + tid), stream_load(q + D + tid)};
-            } else {
-                dst[n2] = stream_load(reinterpret_cast<const f2*>(p0 + 512 * n2) + tid);
-            }
-        }
+        for (int n2 = 0; n2 < 16; ++n2) dst[n2] = row(p0, n2);
     };
     // GEN: the pair (x[o + 256 n2 + tid], x[o + D + 256 n2 + tid]) for n2 = 0..15 (o >= 0,
     // wave-uniform).  A row of 256 consecutive samples touches at most two generator

@@ -31,6 +31,7 @@
 namespace sdr_amd {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
     constexpr int OT = 4096 / P;         // outputs per plane per tile
     constexpr int G = OT / 1024;         // 256-output column groups per wave per plane
     constexpr int NIDX = OT + HB;        // staged samples per plane
-    constexpr int PS = NIDX + 2 * (NIDX / 16) + 2; // floats per plane in LDS (row stride 18 per 16 samples)
+    constexpr int PS = NIDX + 2 * (NIDX / 16) + 2; // padded samples in LDS (row stride 18 per 16 samples), x P floats
     constexpr int NC = (4096 + P * HB) / 4; // 16-byte chunks to stage
     extern __shared__ __align__(16) float lds[];
 
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
     src.hist_len = a.hist_len;
     src.vec_ok = a.vec_in;
 
-    // ---- stage the tile and its left halo, de-interleaving the planes ---------------------
+    // ---- stage the tile and its left halo.  LDS keeps the planes interleaved as in memory:
+    // sample idx of plane p sits at float P * (idx + 2 * (idx >> 4)) + p (row stride 18 samples per
+    // 16), so the B operands of the P planes of one column group come out of ONE ds_read of 4 P
+    // bytes per lane, conflict-free (lane address 18 j + kk samples: the 64 lanes of a b32 / b64
+    // read, and the 16-lane groups of a b128 read, fall on different banks).
     const long long F0 = (long long)P * (tile * OT - HB); // first float of the staged range (stream float index)
     constexpr int ROUNDS = (NC + 255) / 256;
     f4 st[ROUNDS];
@@ -110,11 +115,13 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
     for (int r = 0; r < ROUNDS; ++r) {
         const int ci = tid + 256 * r;
         if (ci < NC) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int fi = 4 * ci + e;
-                const int p = fi % P, idx = fi / P;
-                lds[p * PS + idx + 2 * (idx >> 4)] = st[r][e];
+            const int idx0 = 4 * ci / P;                          // first sample of the chunk (4 / P samples, one 16-group)
+            float* dst = lds + P * (idx0 + 2 * (idx0 >> 4));
+            if constexpr (P == 1) {                               // 8-byte aligned only
+                *reinterpret_cast<f2v*>(dst) = f2v{st[r][0], st[r][1]};
+                *reinterpret_cast<f2v*>(dst + 2) = f2v{st[r][2], st[r][3]};
+            } else {
+                *reinterpret_cast<f4*>(dst) = st[r];
             }
         }
     }
@@ -122,22 +129,30 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
 
     // ---- 4 accumulators per wave: chain c = (column group gq, plane p) ----------------------
     f4 acc[4];
-    const float* bptr[4];
     const int j = lane & 15, kk = lane >> 4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        acc[c] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int gq = c / P, p = c % P;
-        const int base = (w * G + gq) * 256; // plane-sample offset of the group inside the tile (multiple of 16)
-        bptr[c] = lds + p * PS + base + 2 * (base >> 4) + 18 * j + kk;
-    }
+    for (int c = 0; c < 4; ++c) acc[c] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     static_assert(G * P == 4, "four chains per wave");
+    // lane's first B sample of column group gq: group base (multiple of 16) + 16 j + kk
+    const float* bbase = lds + P * ((w * G) * 288 + 18 * j + kk); // 256 samples = 288 padded
 #pragma unroll
     for (int s = 0; s < SMAX; ++s) {
+        const int off = 4 * s + 2 * (s >> 2); // samples; compile-time per step
+        if constexpr (P == 1) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float b = bptr[c][4 * s + 2 * (s >> 2)];
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], b, acc[c], 0, 0, 0);
+            for (int gq = 0; gq < 4; ++gq)
+                acc[gq] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], bbase[gq * 288 + off], acc[gq], 0, 0, 0);
+        } else if constexpr (P == 2) {
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                const f2v b = *reinterpret_cast<const f2v*>(bbase + 2 * (gq * 288 + off));
+                acc[2 * gq] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], b.x, acc[2 * gq], 0, 0, 0);
+                acc[2 * gq + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], b.y, acc[2 * gq + 1], 0, 0, 0);
+            }
+        } else {
+            const f4 b = *reinterpret_cast<const f4*>(bbase + 4 * off);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s], b[p], acc[p], 0, 0, 0);
         }
     }
 
@@ -150,12 +165,23 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
     __syncthreads();
     static_assert(P * PS >= 4096 + 4 * 64, "the staged planes are large enough to hold the tile's outputs");
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int gq = c / P, p = c % P;
+    for (int gq = 0; gq < G; ++gq) {
+        const int f0 = P * ((w * G + gq) * 256 + 16 * j + 4 * kk); // float index inside the tile, multiple of 4 P
+        if constexpr (P == 1) {
+            *reinterpret_cast<f4*>(&lds[f0 + 4 * (f0 >> 6)]) = acc[gq];
+        } else if constexpr (P == 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = P * ((w * G + gq) * 256 + 16 * j + 4 * kk + r) + p; // float index inside the tile
-            lds[f + 4 * (f >> 6)] = acc[c][r];
+            for (int h = 0; h < 2; ++h) {   // floats f0 + 4 h .. + 3 = samples 2 h, 2 h + 1 of both planes
+                const int f = f0 + 4 * h;
+                *reinterpret_cast<f4*>(&lds[f + 4 * (f >> 6)]) =
+                    f4{acc[2 * gq][2 * h], acc[2 * gq + 1][2 * h], acc[2 * gq][2 * h + 1], acc[2 * gq + 1][2 * h + 1]};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + 4 * r;
+                *reinterpret_cast<f4*>(&lds[f + 4 * (f >> 6)]) = f4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();

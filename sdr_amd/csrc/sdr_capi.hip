@@ -176,7 +176,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // its memory-bound floor (5.7-6.0 TB/s) up to 32 dense taps (40 on real samples) or ~87
     // Hilbert-structured taps; from there the fast convolution is quicker.
     const size_t fft_from = stride == 2 ? 88u : sample_kind == SDR_COMPLEX ? 33u : 41u;
-    bool use_fft = ntaps >= fft_from && fft_parts <= 64;
+    bool use_fft = ntaps >= fft_from && fft_parts <= 64;   // (the matrix-core kernel may still take over below)
 #ifdef SDR_AMD_DIAG
     if (const char* ev = getenv("SDR_AMD_FFT")) use_fft = atoi(ev) != 0 && fft_parts <= 64;
 #endif
@@ -196,7 +196,14 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     f->use_fft = use_fft;
     // matrix-core direct form: dense (or every-other-tap) filters of up to 129 kept taps
     const int mfma_smax = (shift == 0) ? mfma_steps_for(plan.kept) : 0;
-    const bool use_mfma = !use_fft && path == SDR_PATH_MFMA;
+    // Measured three-way crossover (profiles/r02_direct_vs_fft_vs_mfma.txt): with 17..49 kept taps
+    // (dense, or every other tap of a Hilbert design up to 97 taps) the matrix-core kernel holds
+    // 5.4-6.0 TB/s (0.67-0.75 of HBM peak) where the direct form has turned VALU-bound and the
+    // overlap-save kernel sits at 5.1-5.3; below, the direct form is level or ahead; from 50 kept
+    // taps up the fp32 matrix pipe is the bottleneck and the overlap-save kernel is faster.
+    const bool mfma_auto = path == SDR_PATH_AUTO && mfma_smax != 0 && plan.kept >= 17 && plan.kept <= 49;
+    if (mfma_auto) f->use_fft = use_fft = false;
+    const bool use_mfma = mfma_auto || (!use_fft && path == SDR_PATH_MFMA);
     if (use_mfma && mfma_smax == 0) {
         delete f;
         return fail(SDR_ERR_INVALID, "sdr_fir_create: no matrix-core kernel for this filter (more than 129 kept taps, or odd-phase taps)");

@@ -277,3 +277,49 @@ def test_config5_sharding_recipe_on_one_gpu(world):
     # two fp32 results whose tiles fall at different offsets: each is within ~6e-7 of the
     # exact answer, so they may differ from one another by twice that
     assert rel_err(got, whole) <= 3e-6
+
+
+def test_short_chain_seek_then_generate():
+    """A chain whose fused filter is below the overlap-save crossover (15 taps: direct form) on a
+    rank that does not own the start of the stream: Chain.seek zeroes the histories, so
+    generate_device may still move the filter to the overlap-save kernels (where the generator
+    lives).  The seeked rank's outputs equal the same packets of the stream produced in one go;
+    once the chain has filtered samples through the direct form, the move is refused."""
+    import torch
+    B = 2044
+    cps = float(np.float32(100e3) / np.float32(1e6))
+    stages = [(sdr_amd.hilbert(9), 4), (sdr_amd.fir_lowpass(7, 0.2), 0)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def produce(first, blocks, halo):
+        gen = sdr_amd.Gen("sine", False, 1.0, cps, 0.0, B)
+        chain = sdr_amd.Chain(stages, False)
+        assert chain.ntaps == 15
+        out = torch.empty((blocks + halo) * B, dtype=torch.float32, device="cuda")
+        if first:
+            assert (first - halo) * B >= chain.min_seek
+            gen.advance(first - halo)
+            chain.seek((first - halo) * B)
+            assert chain.generate_device(gen, halo, out.data_ptr(), stream=stream) == halo * B
+        n1 = chain.generate_device(gen, blocks, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        return out[:n1].cpu().numpy()
+
+    whole = produce(0, 12, 0)
+    assert len(whole) == 12 * B - 4
+    tail = produce(5, 7, 1)
+    assert len(tail) == 7 * B
+    assert rel_err(tail, whole[5 * B - 4:]) <= 3e-6
+
+    # the documented bound: min_seek is accepted, one less is not
+    chain = sdr_amd.Chain(stages, False)
+    chain.seek(chain.min_seek)
+    with pytest.raises(sdr_amd.SdrError):
+        chain.seek(chain.min_seek - 1)
+    # a short chain that has already run on the direct-form kernels cannot be moved
+    chain.reset()
+    x = torch.zeros(5000, dtype=torch.float32, device="cuda")
+    chain.process_tensor(x)
+    gen = sdr_amd.Gen("sine", False, 1.0, cps, 0.0, B)
+    with pytest.raises(sdr_amd.SdrError):
+        chain.generate_device(gen, 1, x.data_ptr(), stream=stream)

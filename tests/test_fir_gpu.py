@@ -97,6 +97,20 @@ def test_matrix_core_kernels(kind, ntaps, cplx):
         assert rel_err(y2[c], O.fir(taps, x2[c])) <= TOL, c
 
 
+def test_kernel_family_chosen_by_measured_crossover():
+    """sdr_fir_create picks the family by the measured three-way crossover
+    (profiles/r02_direct_vs_fft_vs_mfma.txt): direct form up to 16 kept taps, the matrix-core
+    kernel for 17..49 kept taps, overlap-save beyond (and for odd-phase Hilbert designs)."""
+    def name(kind, ntaps, cplx):
+        return sdr_amd.FirState(taps_for(kind, ntaps), cplx).kernel_name
+    assert "fir_direct" in name("lowpass", 15, True)
+    assert "fir_mfma" in name("lowpass", 31, True) and "fir_mfma" in name("lowpass", 49, False)
+    assert "fir_mfma" in name("hilbert", 63, False) and "fir_mfma" in name("hilbert", 95, True)
+    assert "fir_fft4096" in name("lowpass", 65, True) and "fir_fft4096" in name("hilbert", 127, False)
+    assert "fir_fft4096" in name("lowpass", 127, True) and "fir_fft4096" in name("bandpass", 4095, True)
+    assert "fir_mfma" not in name("hilbert", 61, False)      # kept taps on the odd phase
+
+
 def test_matrix_core_kernel_refuses_what_it_cannot_do():
     with pytest.raises(sdr_amd.SdrError):
         sdr_amd.FirState(taps_for("lowpass", 255), True, path="mfma")     # 255 dense taps
