@@ -559,7 +559,7 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
                 out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, "
                                                      "separate passes of this command")
-        elif os.path.exists(tj) and args.path == "auto":
+        elif os.path.exists(tj) and args.path == "auto" and world == 1:
             with open(tj) as f:
                 rec = json.load(f)
             out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")

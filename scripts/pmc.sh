@@ -5,7 +5,7 @@ set -u
 TAG=${1:-pmc}; WL=${2:-c2}
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"; export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline ${EXTRA:-}"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
@@ -19,7 +19,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "fir_fft4096" in row["Kernel_Name"] or "fir_direct" in row["Kernel_Name"]:
+        if any(k in row["Kernel_Name"] for k in ("fir_fft4096", "fir_direct", "fir_mfma")):
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k][1:] or acc[k]

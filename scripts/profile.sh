@@ -10,7 +10,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # the same command as the bench line it documents: default steps / warm-up
-ARGS="bench.py --workload $WL --no-cpu-baseline"
+ARGS="bench.py --workload $WL --no-cpu-baseline ${EXTRA:-}"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/bench_trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/bench_trace.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/bench_fetch.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/bench_write.log"; exit 1; }

@@ -52,4 +52,6 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     print("HBM traffic bytes/launch: %.4g" % (rd + wr))
     with open(os.path.join(out, "traffic_%s.json" % wl), "w") as f:
         json.dump({"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr,
-                   "raw_kib": res, "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)"}, f)
+                   "raw_kib": res, "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)",
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --workload %s` "
+                             "(scripts/profile.sh), kernel %s" % (wl, dominant)}, f)

@@ -66,7 +66,14 @@ struct sdr_fir {
     const float* d_wtab = nullptr; // twiddle table, stored behind the spectra in d_hperm
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
-    hipStream_t stream = nullptr; // used by the host-buffer entry points
+    // Host-buffer entry points: one stream per staging slot, so that the device-to-host copy of
+    // batch k (slot s) overlaps the host-to-device copy of batch k+1 (slot s^1) -- PCIe is full
+    // duplex.  The filter kernels still run in submission order: each waits for the event recorded
+    // behind the previous batch's kernels (the history carries from batch to batch).
+    hipStream_t stream = nullptr;  // slot 0; also what reset / destroy synchronise first
+    hipStream_t stream1 = nullptr; // slot 1
+    hipEvent_t filtered = nullptr; // behind the kernels of the latest submission
+    bool have_filtered = false;
     struct Slot {
         float* d_in = nullptr;
         float* d_out = nullptr;
@@ -74,6 +81,7 @@ struct sdr_fir {
         hipEvent_t done = nullptr;
         bool pending = false;
     } slot[2];
+    hipStream_t slot_stream(int s) const { return s ? stream1 : stream; }
 };
 
 extern "C" const char* sdr_version(void) { return "sdr_amd 0.1 (gfx950)"; }
@@ -292,6 +300,8 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&f->stream1, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&f->filtered, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     for (auto& s : f->slot)
         if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     *out = f;
@@ -322,6 +332,7 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (!f) return;
     DeviceGuard guard(f->device);
     if (f->stream) (void)hipStreamSynchronize(f->stream);
+    if (f->stream1) (void)hipStreamSynchronize(f->stream1);
     for (auto& s : f->slot) {
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
@@ -333,6 +344,8 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
     if (f->stream) (void)hipStreamDestroy(f->stream);
+    if (f->stream1) (void)hipStreamDestroy(f->stream1);
+    if (f->filtered) (void)hipEventDestroy(f->filtered);
     delete f;
 }
 
@@ -428,6 +441,7 @@ static int ensure_slot(sdr_fir* f, sdr_fir::Slot& s, size_t floats) {
     if (s.cap >= floats) return SDR_OK;
     // growing a slot: wait for anything that may still use the old buffers
     SDR_HIP(hipStreamSynchronize(f->stream));
+    SDR_HIP(hipStreamSynchronize(f->stream1));
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
     s.d_in = s.d_out = nullptr;
@@ -456,11 +470,15 @@ extern "C" int sdr_fir_submit(sdr_fir_t* f, int slot, const void* in, size_t n, 
     const size_t floats = n * f->channels * f->w;
     int rc = ensure_slot(f, s, floats);
     if (rc != SDR_OK) return rc;
-    SDR_HIP(hipMemcpyAsync(s.d_in, in, floats * sizeof(float), hipMemcpyHostToDevice, f->stream));
-    rc = process_device_impl(f, s.d_in, n, n, s.d_out, n, f->stream);
+    hipStream_t st = f->slot_stream(slot);
+    SDR_HIP(hipMemcpyAsync(s.d_in, in, floats * sizeof(float), hipMemcpyHostToDevice, st));
+    if (f->have_filtered) SDR_HIP(hipStreamWaitEvent(st, f->filtered, 0)); // history order across the two streams
+    rc = process_device_impl(f, s.d_in, n, n, s.d_out, n, st);
     if (rc != SDR_OK) return rc;
-    SDR_HIP(hipMemcpyAsync(out, s.d_out, floats * sizeof(float), hipMemcpyDeviceToHost, f->stream));
-    SDR_HIP(hipEventRecord(s.done, f->stream));
+    SDR_HIP(hipEventRecord(f->filtered, st));
+    f->have_filtered = true;
+    SDR_HIP(hipMemcpyAsync(out, s.d_out, floats * sizeof(float), hipMemcpyDeviceToHost, st));
+    SDR_HIP(hipEventRecord(s.done, st));
     s.pending = true;
     return SDR_OK;
 }
@@ -488,7 +506,9 @@ extern "C" int sdr_fir_reset(sdr_fir_t* f) {
     if (!f) return fail(SDR_ERR_INVALID, "sdr_fir_reset: NULL handle");
     DeviceGuard guard(f->device);
     SDR_HIP(hipStreamSynchronize(f->stream));
+    SDR_HIP(hipStreamSynchronize(f->stream1));
     SDR_HIP(hipDeviceSynchronize());
+    f->have_filtered = false;
     const size_t hist_bytes = f->channels * (size_t)f->hist_len * f->w * sizeof(float);
     SDR_HIP(hipMemset(f->d_hist[0], 0, hist_bytes));
     SDR_HIP(hipMemset(f->d_hist[1], 0, hist_bytes));
