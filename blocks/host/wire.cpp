@@ -1,3 +1,6 @@
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE // splice(2)
+#endif
 #include "wire.hpp"
 
 #include <algorithm>
@@ -5,6 +8,7 @@
 #include <fcntl.h>
 #include <poll.h>
 #include <csignal>
+#include <sys/sendfile.h>
 #include <sys/uio.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -69,9 +73,110 @@ void widen_pipe(int fd) {
 #endif
 }
 
+namespace {
+
+// What kind of descriptor (decides which zero-copy call applies).
+struct FdKind {
+    bool fifo = false, regular = false;
+};
+FdKind kind_of(int fd) {
+    FdKind k;
+    struct stat st;
+    if (::fstat(fd, &st) == 0) {
+        k.fifo = S_ISFIFO(st.st_mode);
+        k.regular = S_ISREG(st.st_mode);
+    }
+    return k;
+}
+
+RouteStats g_route_stats;
+
+// Moves up to n payload bytes from in_fd to out_fd without bringing them into user space:
+// splice(2) when either end is a pipe, sendfile(2) from a regular file (the reference's
+// Source::pass, lib/sdr/stream.cpp:251-296); a plain copy loop where neither applies (terminal,
+// socket pairs the kernel refuses).  Returns bytes moved (short at end of input); *ok = false on
+// a write error.
+uint64_t move_payload(int in_fd, int out_fd, uint64_t n, const FdKind& in, const FdKind& out, std::vector<uint8_t>& buf,
+                      bool* ok) {
+    uint64_t moved = 0;
+    bool try_splice = in.fifo || out.fifo, try_sendfile = in.regular;
+    while (moved < n) {
+        const size_t want = static_cast<size_t>(std::min<uint64_t>(n - moved, 1u << 30));
+        ssize_t r = -1;
+        if (try_splice) {
+            r = ::splice(in_fd, nullptr, out_fd, nullptr, want, SPLICE_F_MOVE | (n - moved > want ? SPLICE_F_MORE : 0));
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { try_splice = false; continue; }
+            if (r > 0) g_route_stats.spliced += static_cast<uint64_t>(r);
+        } else if (try_sendfile) {
+            r = ::sendfile(out_fd, in_fd, nullptr, want);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0 && (errno == EINVAL || errno == ENOSYS)) { try_sendfile = false; continue; }
+            if (r > 0) g_route_stats.sent += static_cast<uint64_t>(r);
+        } else {
+            const size_t piece = std::min(want, buf.size());
+            r = ::read(in_fd, buf.data(), piece);
+            if (r < 0 && errno == EINTR) continue;
+            if (r > 0) {
+                if (!write_full(out_fd, buf.data(), static_cast<size_t>(r))) { *ok = false; return moved; }
+                g_route_stats.copied += static_cast<uint64_t>(r);
+            }
+        }
+        if (r < 0) {
+            if (errno == EPIPE || errno == EIO || errno == ENOSPC) *ok = false;
+            break;
+        }
+        if (r == 0) break; // end of input inside the payload
+        moved += static_cast<uint64_t>(r);
+    }
+    return moved;
+}
+
+// Discards up to n payload bytes of in_fd (the reference's Source::drop, lib/sdr/stream.cpp:219-249):
+// a seek on a regular file, a splice into /dev/null on a pipe, read-and-forget otherwise.
+uint64_t skip_payload(int in_fd, uint64_t n, const FdKind& in, std::vector<uint8_t>& buf) {
+    if (in.regular) {
+        const off_t here = ::lseek(in_fd, 0, SEEK_CUR);
+        struct stat st;
+        if (here >= 0 && ::fstat(in_fd, &st) == 0) {
+            const uint64_t left = st.st_size > here ? static_cast<uint64_t>(st.st_size - here) : 0;
+            const uint64_t take = std::min(n, left);
+            if (::lseek(in_fd, static_cast<off_t>(take), SEEK_CUR) >= 0) {
+                g_route_stats.skipped += take;
+                return take;
+            }
+        }
+    }
+    static int null_fd = -2;
+    if (in.fifo && null_fd == -2) null_fd = ::open("/dev/null", O_WRONLY);
+    uint64_t done = 0;
+    bool try_splice = in.fifo && null_fd >= 0;
+    while (done < n) {
+        const size_t want = static_cast<size_t>(std::min<uint64_t>(n - done, 1u << 30));
+        ssize_t r;
+        if (try_splice) {
+            r = ::splice(in_fd, nullptr, null_fd, nullptr, want, SPLICE_F_MOVE);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) { try_splice = false; continue; }
+        } else {
+            r = ::read(in_fd, buf.data(), std::min(want, buf.size()));
+            if (r < 0 && errno == EINTR) continue;
+        }
+        if (r <= 0) break;
+        done += static_cast<uint64_t>(r);
+        g_route_stats.skipped += static_cast<uint64_t>(r);
+    }
+    return done;
+}
+
+} // namespace
+
+const RouteStats& route_stats() { return g_route_stats; }
+
 bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, void*), void* ctx) {
     widen_pipe(in_fd);
     widen_pipe(out_fd);
+    const FdKind in_kind = kind_of(in_fd), out_kind = kind_of(out_fd);
     std::vector<uint8_t> buf(4u << 20);
     GatherWriter out(out_fd);
     size_t end = 0;          // valid bytes in buf
@@ -79,6 +184,18 @@ bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, 
     bool forwarding = false;   // ... and whether they are forwarded
     bool ok = true;
     for (;;) {
+        // A payload that reaches well beyond what has been read never enters user space: it is
+        // spliced (or sent, or seeked over) descriptor to descriptor -- the reference's zero-copy
+        // pass / drop (lib/sdr/stream.cpp:219-296), applied where it pays: packets of ~8 KiB are
+        // cheaper through the gathered path below (a few system calls per megabyte instead of
+        // three per packet).
+        if (end == 0 && payload_left >= kZeroCopyFrom) {
+            const uint64_t got = forwarding ? move_payload(in_fd, out_fd, payload_left, in_kind, out_kind, buf, &ok)
+                                            : skip_payload(in_fd, payload_left, in_kind, buf);
+            if (!ok || got < payload_left) break; // write error, or the input ended inside the payload
+            payload_left = 0;
+            continue;
+        }
         ssize_t r = ::read(in_fd, buf.data() + end, buf.size() - end);
         if (r < 0 && errno == EINTR) continue;
         if (r <= 0) break; // end of stream (a partial header in buf[0, end) is dropped)

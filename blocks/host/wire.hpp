@@ -50,6 +50,27 @@ void ignore_sigpipe();
 // True when a read on fd would not block right now (data or EOF pending).
 bool input_ready(int fd);
 
+// Packet routing without touching payloads (the reference's Source::pass / Source::drop,
+// lib/sdr/stream.cpp:219-364, which splice packet by packet).  Two regimes:
+//   * small packets (the ~8 KiB ones `gen` emits): the stream is read in large pieces, headers
+//     are parsed in place, and every run of consecutive forwarded packets leaves in ONE gathered
+//     write straight from the read buffer -- two copies per byte but a few system calls per
+//     megabyte instead of three per packet;
+//   * a payload that extends kZeroCopyFrom bytes or more beyond what has been read is moved
+//     descriptor to descriptor like the reference does: splice(2) when an end is a pipe,
+//     sendfile(2) from a regular file; a dropped one is seeked over (file) or spliced into
+//     /dev/null (pipe).  No byte of it enters user space.
+// A short final payload is forwarded as far as it arrived, behind its unchanged header; a short
+// final header ends the stream.  Returns false if a write failed.
+constexpr uint64_t kZeroCopyFrom = 64u << 10;
+bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, void*), void* ctx);
+// Bytes route_packets moved by each mechanism so far in this process (stream-filter prints them
+// to stderr when SDR_AMD_ROUTE_STATS is set: tests and curiosity).
+struct RouteStats {
+    uint64_t spliced = 0, sent = 0, copied = 0, skipped = 0;
+};
+const RouteStats& route_stats();
+
 // Sequential packet reader over a byte stream (semantics of the reference's
 // Source::next/recv/drop, lib/sdr/stream.cpp:121-249: unread payload of the
 // previous packet is discarded by next(); a short header is a clean EOF; a short
@@ -58,15 +79,6 @@ bool input_ready(int fd);
 // headers and payloads are served from that buffer -- with ~8 KiB packets a system call
 // per header and per payload is what bounds a block's throughput otherwise.  A refill
 // never waits for more than the first byte, so an interactive pipe sees no added latency.
-// Packet routing without touching payloads (the reference's Source::pass / Source::drop,
-// lib/sdr/stream.cpp:219-364, which splice packet by packet): the stream is read in large
-// pieces, headers are parsed in place, and every run of consecutive forwarded packets leaves
-// in ONE gathered write straight from the read buffer -- two copies per byte but a few
-// system calls per megabyte instead of three per packet.  A short final payload is forwarded
-// as far as it arrived, behind its unchanged header; a short final header ends the stream.
-// Returns false if a write failed.
-bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, void*), void* ctx);
-
 class PacketReader {
 public:
     explicit PacketReader(int fd = 0);

@@ -99,6 +99,11 @@ int main(int argc, char* argv[]) {
         // the reference block: pure packet routing on the host, payloads never looked at
         (void)host::route_packets(0, 1, forward_cb, &rule);
         host::PacketWriter(1).flush_to_disk();
+        if (std::getenv("SDR_AMD_ROUTE_STATS")) {
+            const host::RouteStats& st = host::route_stats();
+            std::cerr << "route: spliced=" << st.spliced << " sendfile=" << st.sent << " copied=" << st.copied
+                      << " skipped=" << st.skipped << std::endl;
+        }
         return 0;
     }
 

@@ -13,15 +13,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 $ARGS > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/p$i.log"; exit 1; }
 done
-python3 - "$OUT" <<'PY'
-import csv, glob, os, sys, collections
-out = sys.argv[1]
-acc = collections.defaultdict(list)
-for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        if any(k in row["Kernel_Name"] for k in ("fir_fft4096", "fir_direct", "fir_mfma")):
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k in sorted(acc):
-    v = acc[k][1:] or acc[k]
-    print("%-26s %.6g" % (k, sum(v) / len(v)))
-PY
+python3 scripts/summarize_pmc.py "$OUT"

@@ -214,3 +214,58 @@ def test_stream_filter_routing_in_dribbles_and_bulk():
     proc.stdin.close()
     t.join()
     assert proc.wait() == 0 and out[0] == want
+
+
+@pytest.mark.parametrize("stdin_kind,stdout_kind", [("pipe", "pipe"), ("file", "pipe"), ("pipe", "file"), ("file", "file")])
+def test_stream_filter_zero_copy_pass_and_drop(tmp_path, stdin_kind, stdout_kind):
+    """Large payloads never enter user space (the reference's Source::pass / drop,
+    lib/sdr/stream.cpp:219-296): what lies beyond the bytes already read is spliced when an end is a
+    pipe, sent with sendfile from a regular file, and a dropped payload is seeked over or spliced
+    into /dev/null.  Output bytes are checked against the routing predicate; the mechanism against
+    the block's own byte counters (SDR_AMD_ROUTE_STATS)."""
+    import re
+    rng = np.random.default_rng(11)
+    sizes = [8176, 6 << 20, 100, 9 << 20, 8176, 3 << 20, 12 << 20, 40]
+    ids = [1, 1, 2, 2, 1, 2, 1, 1]
+    pk = [HDR.pack(i, 6, n, k) + rng.integers(0, 256, n, dtype=np.uint8).tobytes() for k, (i, n) in enumerate(zip(ids, sizes))]
+    stream = b"".join(pk)
+    want = b"".join(p for p, i in zip(pk, ids) if i == 1)
+    src = tmp_path / "in.bin"
+    src.write_bytes(stream)
+    dst = tmp_path / "out.bin"
+    env = dict(os.environ, SDR_AMD_ROUTE_STATS="1")
+    fin = open(src, "rb") if stdin_kind == "file" else subprocess.PIPE
+    fout = open(dst, "wb") if stdout_kind == "file" else subprocess.PIPE
+    proc = subprocess.Popen([os.path.join(BIN, "stream-filter"), "pass", "1"], stdin=fin, stdout=fout, stderr=subprocess.PIPE, env=env)
+    import threading
+    got = []
+    readers = [threading.Thread(target=lambda: got.append(proc.stdout.read()))] if stdout_kind == "pipe" else []
+    err = []
+    readers.append(threading.Thread(target=lambda: err.append(proc.stderr.read())))
+    for t in readers:
+        t.start()
+    if stdin_kind == "pipe":
+        proc.stdin.write(stream)
+        proc.stdin.close()
+    assert proc.wait(timeout=120) == 0
+    for t in readers:
+        t.join()
+    if stdout_kind == "file":
+        fout.close()
+        out = dst.read_bytes()
+    else:
+        out = got[0]
+    if stdin_kind == "file":
+        fin.close()
+    assert out == want
+    m = re.search(r"route: spliced=(\d+) sendfile=(\d+) copied=(\d+) skipped=(\d+)", err[0].decode())
+    assert m, err[0]
+    spliced, sent, copied, skipped = map(int, m.groups())
+    big_pass = (6 << 20) + (12 << 20)          # forwarded payload bytes in packets larger than a read
+    big_drop = (9 << 20) + (3 << 20)
+    assert copied == 0
+    if stdin_kind == "pipe" or stdout_kind == "pipe":
+        assert spliced >= big_pass - (5 << 20) * 2 and sent == 0   # all but what the first reads already held
+    else:
+        assert sent >= big_pass - (5 << 20) * 2 and spliced == 0
+    assert skipped >= big_drop - (5 << 20) * 2
