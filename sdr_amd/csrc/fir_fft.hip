@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
 }
 
 template <bool REAL, bool GEN>
-static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t stream, const FftSide* side) {
+static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t stream) {
     const dim3 b(256);
     const int n_short = a.grid_carry + a.grid_edge;
     if (a.parts > 1) {
@@ -699,21 +699,9 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
             if (a.parts == 2 && !(SDR_ABLATE(a) & 4)) hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, true, true, GEN>), g, b, 0, stream, a);
             else hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, false, false, GEN>), g, b, 0, stream, a);
         }
-        if (n_short > 0) {
-            if (side && grid_int > 0) {
-                // fork: the short launch waits for whatever precedes this call on `stream`, runs on the
-                // side stream beside the main kernel, and `stream` joins it before the next operation
-                hipError_t e = hipEventRecord(side->fork, stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN>), dim3((unsigned)n_short), b, 0, side->stream, a);
-                e = hipEventRecord(side->join, side->stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(stream, side->join, 0);
-                if (e != hipSuccess) return e;
-            } else {
-                hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN>), dim3((unsigned)n_short), b, 0, stream, a);
-            }
-        }
+        // (forking this short launch onto a side stream so that it runs beside the main kernel was
+        // tried: the two event hand-offs cost more than the 17 us it hides, C3 0.456 -> 0.480 ms)
+        if (n_short > 0) hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN>), dim3((unsigned)n_short), b, 0, stream, a);
         return hipGetLastError();
     }
     const dim3 g((unsigned)(grid_int + n_short));
@@ -742,7 +730,7 @@ void fir_fft_plan(size_t ntaps, int* halo, int* parts) {
     *parts = (int)((ntaps + 2047) / 2048);
 }
 
-hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStream_t stream, const FftSide* side) {
+hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStream_t stream) {
     if (a0.n == 0 || a0.channels == 0) return hipSuccess;
     if (a0.gen.enabled && (!real || a0.channels != 1 || a0.gen.block_size < 256 || a0.gen.block_size > (1 << 23)))
         return hipErrorInvalidValue;
@@ -773,8 +761,8 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     a.grid_edge = (int)(edge < grid_blocks ? edge : grid_blocks);
     const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
     a.grid_carry = a.new_hist ? (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64) : 0;
-    if (a.gen.enabled) return launch_tiles<true, true>(a, grid_int, stream, side);
-    return real ? launch_tiles<true, false>(a, grid_int, stream, side) : launch_tiles<false, false>(a, grid_int, stream, side);
+    if (a.gen.enabled) return launch_tiles<true, true>(a, grid_int, stream);
+    return real ? launch_tiles<true, false>(a, grid_int, stream) : launch_tiles<false, false>(a, grid_int, stream);
 }
 
 const char* fir_fft_kernel_name(bool real) { return real ? "fir_fft4096<REAL>" : "fir_fft4096<COMPLEX>"; }

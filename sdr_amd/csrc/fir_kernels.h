@@ -53,14 +53,7 @@ struct FftArgs {
     int grid_carry, grid_edge; // set by launch_fir_fft: leading workgroups that carry the history / take edge tiles
     GenSrc gen;           // gen.enabled: samples 0..n-1 are synthesised (real, one channel), `in` is unused
 };
-// Partitioned filters run their carry / edge workgroups as a launch of their own; with a side
-// stream and two events it is forked off the caller's stream and runs beside the main kernel
-// (profiles/r02_c3_summary.txt: 17 us behind a 431 us kernel when serialised).
-struct FftSide {
-    hipStream_t stream;
-    hipEvent_t fork, join;
-};
-hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream, const FftSide* side = nullptr);
+hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
 const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);
 

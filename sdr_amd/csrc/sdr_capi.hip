@@ -64,7 +64,6 @@ struct sdr_fir {
     int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
     float* d_hperm = nullptr;
     const float* d_wtab = nullptr; // twiddle table, stored behind the spectra in d_hperm
-    FftSide side = {nullptr, nullptr, nullptr}; // partitioned filters: side stream for the carry / edge launch
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     // Host-buffer entry points: one stream per staging slot, so that the device-to-host copy of
@@ -302,11 +301,6 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     if ((e = hipStreamCreateWithFlags(&f->stream1, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    if (use_fft && fft_parts > 1) {
-        if ((e = hipStreamCreateWithFlags(&f->side.stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-        if ((e = hipEventCreateWithFlags(&f->side.fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&f->side.join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    }
     if ((e = hipEventCreateWithFlags(&f->filtered, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     for (auto& s : f->slot)
         if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -351,12 +345,6 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     if (f->stream1) (void)hipStreamDestroy(f->stream1);
-    if (f->side.stream) {
-        (void)hipStreamSynchronize(f->side.stream);
-        (void)hipStreamDestroy(f->side.stream);
-    }
-    if (f->side.fork) (void)hipEventDestroy(f->side.fork);
-    if (f->side.join) (void)hipEventDestroy(f->side.join);
     if (f->filtered) (void)hipEventDestroy(f->filtered);
     delete f;
 }
@@ -394,7 +382,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.ablate = f->fft_ablate;
         fa.contig = f->fft_contig;
         fa.new_hist = f->d_hist[f->cur ^ 1];
-        SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream, f->side.stream ? &f->side : nullptr));
+        SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         f->cur ^= 1;
         return SDR_OK;
     }
@@ -855,7 +843,7 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.gen.waveform = g->waveform;
     fa.gen.enabled = 1;
     fa.new_hist = f->d_hist[f->cur ^ 1];
-    SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream, f->side.stream ? &f->side : nullptr));
+    SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
     f->cur ^= 1;
     SDR_HIP(hipEventRecord(t->free, stream));
     return SDR_OK;
