@@ -1,0 +1,149 @@
+// membench10.hip -- round 2: WHY does a looping workgroup move fewer bytes than one-tile workgroups
+// (r02_membench_runs.txt: 5.2-5.4 against 5.9-6.0 TB/s)?  Hypothesis: hardware dispatch keeps the tiles in
+// flight a dense, ordered window of the buffers; grid-strided persistent workgroups drift apart (CUs differ
+// in memory latency), the window widens, DRAM rows and translations are shared by fewer accesses.
+// Test: persistent workgroups that take their tiles from a global ticket counter IN ORDER, the ticket for
+// the tile after next fetched while the current tile is in flight (no exposed atomic latency; the r01
+// "atomic queue" of membench4 had it exposed and two extra barriers per tile).
+//   MODE 0: persistent, grid-strided      MODE 1: persistent, ordered tickets      MODE 2: one tile per workgroup
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int ROWS, int HALO, int MODE, int NC>
+__global__ __launch_bounds__(256) void copy_os(const f2* __restrict__ in, f2* __restrict__ out, long long tiles,
+                                               unsigned* counter, int xch, int ops) {
+    extern __shared__ f2 lds[];
+    __shared__ unsigned ticket_box;
+    const int tid = threadIdx.x;
+    constexpr long long L = ROWS * 256 - HALO;
+    long long t = blockIdx.x;
+    if (t >= tiles) return;
+    long long tn = MODE == 2 ? tiles : t + gridDim.x; // the first two tiles of a workgroup are static
+    f2 nx[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) nx[k] = __builtin_nontemporal_load(&in[t * L + 256 * k + tid]);
+    while (true) {
+        f2 v[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) v[k] = nx[k];
+        const bool more = tn < tiles;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) nx[k] = __builtin_nontemporal_load(&in[tn * L + 256 * k + tid]);
+        }
+        unsigned ticket = 0;
+        if (MODE == 1 && tid == 0) ticket = atomicAdd(counter + 64 * (blockIdx.x % NC), 1u); // tile after next; NC counters, 256 B apart
+        for (int x = 0; x < xch; ++x) {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) lds[k * 264 + tid] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) v[k] = lds[(tid >> 5) * 264 + 32 * k + (tid & 31)];
+            __syncthreads();
+        }
+        for (int o = 0; o < ops; o += ROWS) {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) v[k] = __builtin_elementwise_fma(v[k], f2{1.0f, 1.0f}, v[(k + 1) % ROWS] * 1e-30f);
+        }
+#pragma unroll
+        for (int k = HALO / 256; k < ROWS; ++k) {
+            if (k == HALO / 256 && HALO % 256 != 0 && tid < HALO % 256) continue;
+            __builtin_nontemporal_store(v[k], &out[t * L + 256 * k + tid - HALO]);
+        }
+        if (!more) break;
+        t = tn;
+        if (MODE == 1) {
+            if (tid == 0) ticket_box = ticket;
+            __syncthreads();
+            tn = 2LL * gridDim.x + (long long)ticket_box * NC + blockIdx.x % NC;
+            __syncthreads();
+        } else {
+            tn = t + gridDim.x;
+        }
+    }
+}
+
+template <int ROWS, int HALO, int MODE, int NC = 8>
+static void run(const f2* in, f2* out, unsigned* counter, long long n, int wg_per_cu, int gpc, int xch, int ops) {
+    constexpr long long L = ROWS * 256 - HALO;
+    const long long tiles = (n - ROWS * 256) / L + 1;
+    size_t lds = ((size_t)(160 * 1024 / wg_per_cu) - 64) & ~(size_t)255;
+    if (lds < (size_t)ROWS * 264 * 8) { printf("LDS too small\n"); return; }
+    auto fn = copy_os<ROWS, HALO, MODE, NC>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long grid = MODE == 2 ? tiles : 256LL * gpc;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (MODE == 1) CK(hipMemsetAsync(counter, 0, 64 * 256, 0));
+        hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, 0, in, out, tiles, counter, xch, ops);
+    };
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipDeviceSynchronize());
+    const int reps = 30;
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const char* names[3] = {"persistent grid-stride ", "persistent ordered tick", "one tile per workgroup "};
+    printf("tile %2d KB halo %3d %s (%2d counters) grid %2d/CU resident %d/CU xch %d ops %3d: %.3f ms %5.0f GB/s (outputs x 16 B)\n", ROWS * 2, HALO,
+           names[MODE], MODE == 1 ? NC : 0, MODE == 2 ? 0 : gpc, wg_per_cu, xch, ops, ms, 2.0 * tiles * L * sizeof(f2) / ms / 1e6);
+    fflush(stdout);
+}
+
+int main() {
+    const long long n = 1LL << 28;
+    f2 *in, *out;
+    unsigned* counter;
+    CK(hipMalloc(&in, n * sizeof(f2)));
+    CK(hipMalloc(&out, n * sizeof(f2)));
+    CK(hipMalloc(&counter, 64 * 256));
+    CK(hipMemset(in, 1, n * sizeof(f2)));
+    CK(hipMemset(out, 0, n * sizeof(f2)));
+    printf("# copy only\n");
+    run<8, 128, 2>(in, out, counter, n, 4, 0, 0, 0);
+    run<8, 128, 0>(in, out, counter, n, 4, 4, 0, 0);
+    run<8, 128, 1>(in, out, counter, n, 4, 4, 0, 0);
+    run<8, 128, 0>(in, out, counter, n, 4, 8, 0, 0);
+    run<8, 128, 1>(in, out, counter, n, 4, 8, 0, 0);
+    run<16, 128, 2>(in, out, counter, n, 3, 0, 0, 0);
+    run<16, 128, 0>(in, out, counter, n, 3, 3, 0, 0);
+    run<16, 128, 1>(in, out, counter, n, 3, 3, 0, 0);
+    run<16, 128, 0>(in, out, counter, n, 3, 9, 0, 0);
+    run<16, 128, 1>(in, out, counter, n, 3, 9, 0, 0);
+    run<16, 128, 0>(in, out, counter, n, 4, 4, 0, 0);
+    run<16, 128, 1>(in, out, counter, n, 4, 4, 0, 0);
+    run<16, 128, 1, 1>(in, out, counter, n, 3, 3, 0, 0);
+    run<16, 128, 1, 32>(in, out, counter, n, 3, 3, 0, 0);
+    run<16, 128, 1, 64>(in, out, counter, n, 3, 3, 0, 0);
+    run<8, 128, 1, 32>(in, out, counter, n, 4, 4, 0, 0);
+    run<8, 128, 1, 64>(in, out, counter, n, 4, 4, 0, 0);
+    printf("# with stand-in work (2 exchanges + packed ops)\n");
+    run<16, 128, 2>(in, out, counter, n, 3, 0, 2, 688);
+    run<16, 128, 0>(in, out, counter, n, 3, 3, 2, 688);
+    run<16, 128, 1>(in, out, counter, n, 3, 3, 2, 688);
+    run<16, 128, 0>(in, out, counter, n, 4, 4, 2, 688);
+    run<16, 128, 1>(in, out, counter, n, 4, 4, 2, 688);
+    run<8, 128, 0>(in, out, counter, n, 4, 4, 2, 328);
+    run<8, 128, 1>(in, out, counter, n, 4, 4, 2, 328);
+    printf("# exchanges and counters, 32 KB tiles, 3 per CU\n");
+    for (int xch : {2, 4, 6}) {
+        run<16, 128, 0>(in, out, counter, n, 3, 9, xch, 688);
+        run<16, 128, 1, 2>(in, out, counter, n, 3, 3, xch, 688);
+        run<16, 128, 1, 4>(in, out, counter, n, 3, 3, xch, 688);
+        run<16, 128, 1, 8>(in, out, counter, n, 3, 3, xch, 688);
+    }
+    run<16, 128, 1, 2>(in, out, counter, n, 3, 3, 0, 0);
+    run<16, 128, 1, 4>(in, out, counter, n, 3, 3, 0, 0);
+    CK(hipFree(in));
+    CK(hipFree(out));
+    return 0;
+}

@@ -48,6 +48,11 @@
 #ifndef SDR_SPREAD
 #define SDR_SPREAD 2
 #endif
+// which ticket counter a workgroup draws from: 0 = bid % FFT_TICKETS (one counter per XCD under round-robin
+// dispatch), 1 = (bid / 8) % FFT_TICKETS (every counter's workgroups spread over all XCDs)
+#ifndef SDR_TICKET_MAP
+#define SDR_TICKET_MAP 0
+#endif
 
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
 // memory pattern.  The release library compiles the switch out.
@@ -442,6 +447,25 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     };
 
     if (inner <= 0 || (long long)bid >= total) return;
+    // Ordered hand-out (single-spectrum and uncached partitioned variants): a workgroup's first two
+    // tiles are bid and bid + nblk; every later one comes from a global ticket counter, in order.
+    // Hardware dispatch keeps the tiles in flight a dense window of the buffers; grid-strided
+    // persistent workgroups drift apart (CUs differ in memory latency), the window widens and the
+    // same loop moves 5.0-5.4 TB/s where ordered tickets move 5.7 (profiles/r02_membench_tickets.txt).
+    // The ticket for the tile after next is fetched at the top of a tile and published through one
+    // LDS word at the inverse transform's block barrier: no exposed latency, no extra barrier.
+    // FFT_TICKETS counters (a workgroup uses counter bid % FFT_TICKETS; one counter serialises at
+    // ~12 ns per ticket, C2 needs one per 11 ns; more counters = looser order = slower).  Flat index g = channel * inner + tile (host: total < 2^31 in this mode).
+    const bool ticketed = !CACHE && !runs && a.tickets != nullptr && !(SDR_ABLATE(a) & 1);
+    unsigned* const tbox = reinterpret_cast<unsigned*>(lds + (ROW - 1)); // row 0, column 271: no exchange touches it
+    const int tslot = SDR_TICKET_MAP ? (bid / 8) % FFT_TICKETS : bid % FFT_TICKETS;
+    auto pos_of = [&](long long g) -> Pos {
+        if (g >= total) return Pos{a.channels, a.t_lo};
+        if (a.channels == 1) return Pos{0, a.t_lo + g};
+        const unsigned ch = (unsigned)g / (unsigned)inner;
+        return Pos{(long long)ch, a.t_lo + (long long)((unsigned)g - ch * (unsigned)inner)};
+    };
+    unsigned ticket = 0;
     Pos cur{0, 0};
     long long left = 0;    // CACHE: tiles of this workgroup's run still to do
     long long prev_ch = -1; // CACHE: channel whose X_(b-1) sits in `prev`
@@ -457,6 +481,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         cur.tt = a.t_lo + bid;
         while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
     }
+    Pos nxt = advance(cur); // the tile after `cur`; past the last one: ch >= channels (runs: see `left`)
     f2 nx[GEN ? 1 : 16]; // the next tile's points, loaded one tile ahead (nothing to prefetch with GEN)
     if constexpr (!GEN) load(in_ptr(cur), nx);
     // the lane constants are set up with the first tile's loads already in flight (every
@@ -466,6 +491,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     auto body = [&]() {
         f2 v[16];
         bool after_forward = false;
+        if (!CACHE && ticketed && tid == 0) ticket = atomicAdd(a.tickets + FFT_TICKET_STRIDE * tslot, 1u);
         if (CACHE && prev_ch != cur.ch) {
             // start of a run or of a channel: transform window b-1 once
             fetch(cur, 2048, v);
@@ -485,9 +511,9 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         // that nobody consumes, which keeps the body branch-free; one tile shared by every
         // workgroup stays in L2, where re-loading the workgroup's own tile went out to memory
         // (2304 x 32 KB per C2 launch)
-        Pos nxt = advance(cur);
-        if (runs ? left <= 1 : nxt.ch >= a.channels) nxt = Pos{0, a.t_lo};
-        const float* pn = in_ptr(nxt);
+        Pos pf = nxt;
+        if (runs ? left <= 1 : nxt.ch >= a.channels) pf = Pos{0, a.t_lo};
+        const float* pn = in_ptr(pf);
         f2 w[16];
         if (SDR_ABLATE(a) & 1) {
             if constexpr (!GEN) load(pn, nx);
@@ -534,8 +560,12 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
                 }
             }
             share(IC<S4>{}, IC<S5>{});
-            inverse_tile(w, lds, tid, c, [&] { share(IC<S7>{}, IC<16>{}); }, [&] { share(IC<S5>{}, IC<S6>{}); },
-                         [&] { share(IC<S6>{}, IC<S7>{}); });
+            inverse_tile(w, lds, tid, c,
+                         [&] {
+                             share(IC<S7>{}, IC<16>{});
+                             if (!CACHE && ticketed && tid == 0) *tbox = ticket;
+                         },
+                         [&] { share(IC<S5>{}, IC<S6>{}); }, [&] { share(IC<S6>{}, IC<S7>{}); });
         }
         float* q0 = a.out + (cur.ch * a.out_stride + first_out(cur) - HALO) * W; // &y[-halo] of the tile
 #pragma unroll
@@ -552,7 +582,13 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
                 stream_store(y, reinterpret_cast<f2*>(q0 + 512 * n2) + tid);
             }
         }
-        cur = advance(cur);
+        cur = nxt;
+        if (!CACHE && ticketed) {
+            const unsigned tk = __builtin_amdgcn_readfirstlane(*tbox); // published before the inverse's barrier
+            nxt = pos_of(2LL * nblk + (long long)tk * FFT_TICKETS + tslot);
+        } else {
+            nxt = advance(nxt);
+        }
         --left;
     };
     // First tile peeled so that the loop header sees the same queue of outstanding
@@ -655,6 +691,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     int bid = blockIdx.x;
     LaneConstsT<TBL> c;
+    if (!LONG && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
     // (the partitioned variants keep their short work in a launch of its own,
     // fir_fft4096_short: sharing a kernel with it costs their main loop 20 %)
     if constexpr (!LONG) {
@@ -679,6 +716,8 @@ template <bool REAL, bool GEN>
 __global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * ROW + 256];
     int bid = blockIdx.x;
+    // partitioned filters: this launch follows the main one on the stream and is never empty
+    if (a.parts > 1 && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
     if (bid < a.grid_carry) {
         carry_history<GEN>(a, REAL ? 1 : 2, bid, a.grid_carry);
         return;
@@ -747,6 +786,13 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     // equal shares: with T interior tiles and at most G workgroups every workgroup walks
     // ceil(T/G) tiles (or one fewer), instead of G workgroups of uneven load
     long long grid_int = 0;
+    // ordered tickets: every variant but the spectrum cache (its workgroups walk runs) and the diagnostic
+    // contiguous mode; 32-bit flat tile indices; every workgroup must be resident from the start (a
+    // workgroup that starts late would take its two static tiles at the very end)
+    const bool ticketed = a.tickets && a.parts != 2 && !a.contig && inner > 0 &&
+                          inner * a.channels + 4LL * grid_blocks < (1LL << 31);
+    if (!ticketed) a.tickets = nullptr;
+    else if (a.resident > 0 && grid_blocks > a.resident) grid_blocks = a.resident;
     if (inner > 0) {
         const long long total = inner * a.channels;
         // a short call: at least two tiles per workgroup (its set-up costs about one), down to

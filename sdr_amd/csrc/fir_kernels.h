@@ -52,7 +52,20 @@ struct FftArgs {
     long long t_lo, t_hi; // set by launch_fir_fft: tiles [t_lo, t_hi) of each channel are interior tiles
     int grid_carry, grid_edge; // set by launch_fir_fft: leading workgroups that carry the history / take edge tiles
     GenSrc gen;           // gen.enabled: samples 0..n-1 are synthesised (real, one channel), `in` is unused
+    // Ordered tile hand-out (fir_fft.hip, interior_tiles): FFT_TICKETS counters, FFT_TICKET_STRIDE words
+    // apart, all zero when the launch starts; the launch zeroes `tickets_next`, the set the handle's next
+    // launch will use (launches on one handle are stream-ordered, like the history swap).  NULL: tiles
+    // are grid-strided.
+    unsigned* tickets;
+    unsigned* tickets_next;
+    int resident;         // workgroups of the single-partition kernels resident on the device at once (0: unknown)
 };
+#ifndef SDR_FFT_TICKETS
+#define SDR_FFT_TICKETS 2 // measured 2 / 8 / 32: C2 0.789 / 0.795 / 0.808 ms (one counter serialises at ~12 ns per ticket: too slow)
+#endif
+constexpr int FFT_TICKETS = SDR_FFT_TICKETS;
+constexpr int FFT_TICKET_STRIDE = 64;
+constexpr size_t FFT_TICKET_WORDS = 2 * FFT_TICKETS * FFT_TICKET_STRIDE; // both sets
 hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
 const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);

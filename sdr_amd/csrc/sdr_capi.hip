@@ -64,6 +64,9 @@ struct sdr_fir {
     int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
     float* d_hperm = nullptr;
     const float* d_wtab = nullptr; // twiddle table, stored behind the spectra in d_hperm
+    unsigned* d_tickets = nullptr; // two sets of tile-ticket counters behind the twiddle table (FftArgs::tickets)
+    int tick = 0;                  // the set the next overlap-save launch uses
+    int fft_resident = 0;
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     // Host-buffer entry points: one stream per staging slot, so that the device-to-host copy of
@@ -263,7 +266,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         }
         // partition p holds taps [p*2048, p*2048+2048) (all taps when parts == 1)
         const size_t plen = fft_parts > 1 ? 2048 : ntaps;
-        std::vector<float> hp((size_t)2 * N * (fft_parts + 1)); // spectra, then the twiddle table
+        std::vector<float> hp((size_t)2 * N * (fft_parts + 1) + FFT_TICKET_WORDS); // spectra, the twiddle table, zeroed ticket counters
         for (int m = 0; m < N; ++m) {
             hp[(size_t)2 * N * fft_parts + 2 * m] = (float)cs[m];
             hp[(size_t)2 * N * fft_parts + 2 * m + 1] = (float)-sn[m];
@@ -287,11 +290,13 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         if ((e = hipMemcpy(f->d_hperm, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
             return bail(e, "hipMemcpy(spectrum)");
         f->d_wtab = f->d_hperm + (size_t)2 * N * fft_parts;
+        f->d_tickets = reinterpret_cast<unsigned*>(f->d_hperm + (size_t)2 * N * (fft_parts + 1));
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         // three workgroups are resident per CU (two for the partitioned variants); three rounds of
         // them leave a shorter tail than two (same-box sweep: 9 per CU 1 % ahead of 6, 12 and 16 level)
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 9);
+        f->fft_resident = cus * (fft_parts > 1 ? 2 : 3);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
         f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", grid > 0 ? grid : f->fft_grid));
         f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
@@ -349,6 +354,15 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     delete f;
 }
 
+// ticket counters of one overlap-save launch (FftArgs::tickets): the launch uses one set and zeroes the other
+static void take_tickets(sdr_fir* f, FftArgs& fa) {
+    fa.tickets = f->d_tickets + (size_t)f->tick * FFT_TICKETS * FFT_TICKET_STRIDE;
+    fa.tickets_next = f->d_tickets + (size_t)(f->tick ^ 1) * FFT_TICKETS * FFT_TICKET_STRIDE;
+    fa.resident = env_int("SDR_AMD_FFT_RESIDENT", f->fft_resident);
+    f->tick ^= 1;
+    if (!env_int("SDR_AMD_FFT_TICKETS", 1)) fa.tickets = fa.tickets_next = nullptr; // diagnostic builds only
+}
+
 static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, size_t n, float* d_out,
                                size_t out_stride, hipStream_t stream) {
     if (n == 0) return SDR_OK;
@@ -382,6 +396,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.ablate = f->fft_ablate;
         fa.contig = f->fft_contig;
         fa.new_hist = f->d_hist[f->cur ^ 1];
+        take_tickets(f, fa);
         SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         f->cur ^= 1;
         return SDR_OK;
@@ -843,6 +858,7 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.gen.waveform = g->waveform;
     fa.gen.enabled = 1;
     fa.new_hist = f->d_hist[f->cur ^ 1];
+    take_tickets(f, fa);
     SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
     f->cur ^= 1;
     SDR_HIP(hipEventRecord(t->free, stream));

@@ -162,6 +162,28 @@ def test_two_partition_spectrum_cache(ntaps, cplx, grid):
         assert rel_err(y[c], O.fir(taps, x[c])) <= TOL, c
 
 
+@pytest.mark.parametrize("grid", [2, 5, 0])
+@pytest.mark.parametrize("ntaps,cplx", [(127, True), (127, False), (1000, True), (6000, False)])
+def test_ordered_tile_tickets(ntaps, cplx, grid):
+    """Single-spectrum and uncached partitioned overlap-save: a workgroup's tiles past its first two
+    come from ticket counters that the handle's PREVIOUS launch zeroed.  Small grids make every
+    workgroup draw many tickets across channel boundaries; the call sequence has a launch without
+    interior tiles between two big ones (it must still leave zeroed counters behind) and ends with
+    a reset + replay (same counters, same result)."""
+    rng = np.random.default_rng(ntaps + 7 * grid + cplx)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps)).astype(np.float32)
+    C, n = 3, 140000
+    x = np.stack([rand(rng, n, cplx) for _ in range(C)])
+    st = sdr_amd.FirState(taps, cplx, channels=C, path="fft", grid=grid)
+    cuts = [0, 60000, 60300, 60301, 125000, n]
+    y = np.concatenate([sdr_amd.fir(st, x[:, cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)], axis=1)
+    for c in range(C):
+        assert rel_err(y[c], O.fir(taps, x[c])) <= TOL, c
+    st.reset()
+    y2 = sdr_amd.fir(st, x[:, :60000])
+    assert np.array_equal(y2, y[:, :60000])
+
+
 @pytest.mark.parametrize("kind,ntaps,cplx", CASES)
 def test_single_call_vs_oracle(kind, ntaps, cplx):
     rng = np.random.default_rng(ntaps * 2 + cplx)
