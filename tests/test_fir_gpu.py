@@ -341,6 +341,31 @@ def test_linearity_and_impulse_full_size():
     assert float(y.abs().sum()) == pytest.approx(float(len(pos) * 3.0 * t.abs().sum()), rel=2e-3)
 
 
+@pytest.mark.parametrize("path,ntaps,reach", [("direct", 15, 16), ("mfma", 31, 144), ("fft", 127, 8192)])
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_non_finite_sample_stays_local(path, ntaps, reach, bad):
+    """kfr::fir is a direct form: a NaN / Inf input sample reaches the next `ntaps` outputs and no
+    other.  The direct-form kernel pads its taps with zeros to a whole number of chunks (NaN * 0: up
+    to 15 more outputs); the matrix-core kernel multiplies the explicit zeros of its Toeplitz operand,
+    so up to 144 neighbouring outputs on either side turn NaN too; the overlap-save kernel loses the tile the sample sits in -- for real signals the PAIR of tiles
+    that share one complex transform, up to 8192 samples -- (documented in
+    INTEGRATION.md).  Everything outside that reach matches the oracle."""
+    rng = np.random.default_rng(ntaps)
+    taps = taps_for("lowpass", ntaps)
+    n, p = 30000, 13000
+    x = rand(rng, n, False)
+    x[p] = bad
+    st = sdr_amd.FirState(taps, False, path=path)
+    y = sdr_amd.fir(st, x)
+    want = O.fir(taps, x)
+    assert not np.isfinite(want[p:p + ntaps]).any() and np.isfinite(want[:p]).all() and np.isfinite(want[p + ntaps:]).all()
+    assert not np.isfinite(y[p:p + ntaps]).any()
+    lo, hi = p - reach, p + ntaps + reach
+    assert np.isfinite(y[:lo]).all() and np.isfinite(y[hi:]).all()
+    keep = np.r_[0:lo, hi:n]
+    assert rel_err(y[keep], want[keep]) <= TOL
+
+
 def test_in_place_is_refused():
     """Tiles re-read their neighbours' inputs: the ABI says in and out must not overlap, and
     the library checks rather than filter its own outputs."""
