@@ -66,6 +66,16 @@ __global__ __launch_bounds__(256) void copy_os(const f2* __restrict__ in, f2* __
     }
 }
 
+// pseudo-random fill (the bench's inputs are uniform random floats; a constant byte pattern toggles far fewer lines)
+__global__ void fill_random(unsigned* p, long long nwords) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float f = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f; // uniform [-1, 1)
+        p[i] = __float_as_uint(f);
+    }
+}
+
 template <int ROWS, int HALO, int MODE, int NC = 8>
 static void run(const f2* in, f2* out, unsigned* counter, long long n, int wg_per_cu, int gpc, int xch, int ops) {
     constexpr long long L = ROWS * 256 - HALO;
@@ -134,6 +144,15 @@ int main() {
     run<16, 128, 1>(in, out, counter, n, 4, 4, 2, 688);
     run<8, 128, 0>(in, out, counter, n, 4, 4, 2, 328);
     run<8, 128, 1>(in, out, counter, n, 4, 4, 2, 328);
+    printf("# the same with uniform random floats in the input instead of a constant byte\n");
+    hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (unsigned*)in, 2 * n);
+    CK(hipDeviceSynchronize());
+    run<16, 128, 2>(in, out, counter, n, 3, 0, 0, 0);
+    run<16, 128, 0>(in, out, counter, n, 3, 9, 0, 0);
+    run<16, 128, 1, 2>(in, out, counter, n, 3, 3, 0, 0);
+    run<16, 128, 1, 2>(in, out, counter, n, 3, 3, 2, 688);
+    run<16, 128, 1, 8>(in, out, counter, n, 3, 3, 2, 688);
+    CK(hipMemset(in, 1, n * sizeof(f2)));
     printf("# exchanges and counters, 32 KB tiles, 3 per CU\n");
     for (int xch : {2, 4, 6}) {
         run<16, 128, 0>(in, out, counter, n, 3, 9, xch, 688);

@@ -61,6 +61,25 @@
 #else
 #define SDR_ABLATE(a) 0
 #endif
+// Experiments only (make diag EXTRA=-DSDR_ABL_NOVALU / -DSDR_ABL_NOLDS / -DSDR_ABL_NOBAR (forward barriers); results are garbage):
+// the transform without its butterflies and twiddles, without its LDS traffic, without its block barriers --
+// what each costs the loop (profiles/r02_fft_chain_ablation.txt).
+#ifdef SDR_ABL_NOVALU
+#define SDR_VALU(x)
+#else
+#define SDR_VALU(x) x
+#endif
+#ifdef SDR_ABL_NOLDS
+#define SDR_LDS(x)
+#else
+#define SDR_LDS(x) x
+#endif
+#define SDR_BAR() __syncthreads()
+#ifdef SDR_ABL_NOBAR
+#define SDR_BARF() // the forward transform's barriers only: the inverse's also publishes the tile ticket
+#else
+#define SDR_BARF() __syncthreads()
+#endif
 
 namespace sdr_amd {
 
@@ -232,30 +251,30 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
     // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
-    dft16<false>(v);
+    SDR_VALU(dft16<false>(v));
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.ta(k));
-    if (after_forward) __syncthreads();
+    for (int k = 1; k < 16; ++k) SDR_VALU(v[P16(k)] = cmul(v[P16(k)], c.ta(k)));
+    if (after_forward) SDR_BARF();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[k * ROW + tid] = v[P16(k)];
+    for (int k = 0; k < 16; ++k) SDR_LDS(lds[k * ROW + tid] = v[P16(k)]);
     after_points_left();
-    __syncthreads();
+    SDR_BARF();
     // ---- B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) --------------
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
+    for (int n1 = 0; n1 < 16; ++n1) SDR_LDS(v[n1] = row1[16 * n1 + l16]);
     after_b_reads();
-    dft16<false>(v);
+    SDR_VALU(dft16<false>(v));
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.tb(k));
+    for (int k = 1; k < 16; ++k) SDR_VALU(v[P16(k)] = cmul(v[P16(k)], c.tb(k)));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
+    for (int k = 0; k < 16; ++k) SDR_LDS(row1[k * 17 + l16] = v[P16(k)]);
     after_stage_b();
     __builtin_amdgcn_wave_barrier();
     // ---- C: lane (k0, k1 = l16), over n0 -> k2 ------------------------------------
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) v[n0] = row1[l16 * 17 + n0];
-    dft16<false>(v);
+    for (int n0 = 0; n0 < 16; ++n0) SDR_LDS(v[n0] = row1[l16 * 17 + n0]);
+    SDR_VALU(dft16<false>(v));
 }
 
 // Inverse transform: w[k2] = Y[(tid>>4) + 16 (tid&15) + 256 k2] in (natural k2 order),
@@ -268,30 +287,30 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW;
     // ---- C': over k2 -> n0 --------------------------------------------------------
-    dft16<true>(w);
+    SDR_VALU(dft16<true>(w));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) row1[l16 * 17 + n0] = w[P16(n0)];
+    for (int n0 = 0; n0 < 16; ++n0) SDR_LDS(row1[l16 * 17 + n0] = w[P16(n0)]);
     after_stage_c();
     __builtin_amdgcn_wave_barrier();
     // ---- B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 ----------------------
 #pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = row1[k * 17 + l16];
+    for (int k = 0; k < 16; ++k) SDR_LDS(w[k] = row1[k * 17 + l16]);
     after_b_reads();
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.tb(k));
-    dft16<true>(w);
+    for (int k = 1; k < 16; ++k) SDR_VALU(w[k] = cmulc(w[k], c.tb(k)));
+    SDR_VALU(dft16<true>(w));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) row1[16 * n1 + l16] = w[P16(n1)];
+    for (int n1 = 0; n1 < 16; ++n1) SDR_LDS(row1[16 * n1 + l16] = w[P16(n1)]);
     before_barrier();
-    __syncthreads();
+    SDR_BAR();
     // ---- A': lane r: conj twiddle, over k0 -> n2 ----------------------------------
 #pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = lds[k * ROW + tid];
+    for (int k = 0; k < 16; ++k) SDR_LDS(w[k] = lds[k * ROW + tid]);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.ta(k));
-    dft16<true>(w);
+    for (int k = 1; k < 16; ++k) SDR_VALU(w[k] = cmulc(w[k], c.ta(k)));
+    SDR_VALU(dft16<true>(w));
 }
 
 // Filter spectrum of partition p, bin (tid>>4) + 16 (tid&15) + 256 k2, from L2.
@@ -372,9 +391,14 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         const f2* q = reinterpret_cast<const f2*>(p0 + 512 * n2) + tid;
         return again ? *q : stream_load(q);
     };
+    // SDR_SPREAD >= 4: shares are taken in the order the next tile's first butterflies need the rows
+    // (0,4,8,12, 1,5,9,13, ...) instead of 0..15
     auto load_rows = [&](const float* p0, f2 (&dst)[16], auto lo, auto hi) {
 #pragma unroll
-        for (int n2 = decltype(lo)::value; n2 < decltype(hi)::value; ++n2) dst[n2] = row(p0, n2);
+        for (int i = decltype(lo)::value; i < decltype(hi)::value; ++i) {
+            const int n2 = (SDR_SPREAD >= 4 && !LONG) ? 4 * (i & 3) + (i >> 2) : i;
+            dst[n2] = row(p0, n2);
+        }
     };
     auto load = [&](const float* p0, f2 (&dst)[16]) {
 #pragma unroll
@@ -456,7 +480,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     // LDS word at the inverse transform's block barrier: no exposed latency, no extra barrier.
     // FFT_TICKETS counters (a workgroup uses counter bid % FFT_TICKETS; one counter serialises at
     // ~12 ns per ticket, C2 needs one per 11 ns; more counters = looser order = slower).  Flat index g = channel * inner + tile (host: total < 2^31 in this mode).
-    const bool ticketed = !CACHE && !runs && a.tickets != nullptr && !(SDR_ABLATE(a) & 1);
+    const bool ticketed = !CACHE && !runs && a.tickets != nullptr;
     unsigned* const tbox = reinterpret_cast<unsigned*>(lds + (ROW - 1)); // row 0, column 271: no exchange touches it
     const int tslot = SDR_TICKET_MAP ? (bid / 8) % FFT_TICKETS : bid % FFT_TICKETS;
     auto pos_of = [&](long long g) -> Pos {
@@ -465,7 +489,6 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         const unsigned ch = (unsigned)g / (unsigned)inner;
         return Pos{(long long)ch, a.t_lo + (long long)((unsigned)g - ch * (unsigned)inner)};
     };
-    unsigned ticket = 0;
     Pos cur{0, 0};
     long long left = 0;    // CACHE: tiles of this workgroup's run still to do
     long long prev_ch = -1; // CACHE: channel whose X_(b-1) sits in `prev`
@@ -491,7 +514,17 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     auto body = [&]() {
         f2 v[16];
         bool after_forward = false;
-        if (!CACHE && ticketed && tid == 0) ticket = atomicAdd(a.tickets + FFT_TICKET_STRIDE * tslot, 1u);
+        // The ticket for the tile after next: one atomic by lane 0, issued once the prefetched points have left
+        // their registers (forward transform's first hook: nothing at the top of the tile then waits behind it), its
+        // result first needed when lane 0 publishes it at the inverse transform's barrier.  fir_fft.o is compiled
+        // with the AMDGPU atomic optimizer off (Makefile): that pass rewrites the add into a wave reduction whose
+        // v_readfirstlane sits right behind the atomic, behind an s_waitcnt vmcnt(0) -- every tile then began by
+        // waiting out the atomic AND the previous tile's stores (0.775 ms for the bare copy loop where the
+        // skeleton needs 0.726).
+        unsigned ticket;
+        auto fetch_ticket = [&] {
+            if (!CACHE && ticketed && tid == 0) ticket = atomicAdd(a.tickets + FFT_TICKET_STRIDE * tslot, 1u);
+        };
         if (CACHE && prev_ch != cur.ch) {
             // start of a run or of a channel: transform window b-1 once
             fetch(cur, 2048, v);
@@ -516,9 +549,11 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         const float* pn = in_ptr(pf);
         f2 w[16];
         if (SDR_ABLATE(a) & 1) {
+            fetch_ticket();
             if constexpr (!GEN) load(pn, nx);
 #pragma unroll
             for (int k = 0; k < 16; ++k) w[P16(k)] = v[k];
+
         } else {
             // The next tile's 16 row loads go out in shares spread over this tile's phases: the
             // memory system sees a steadier request stream than one burst per tile.  Share
@@ -526,17 +561,18 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
             // after the pointwise product, C' hook, B' reads, before the inverse's barrier).
             constexpr int LV = SPREAD ? SDR_SPREAD : 0;
             constexpr int S0 = 0;
-            constexpr int S1 = LV == 3 ? 2 : LV == 2 ? 3 : LV == 1 ? 5 : 16; // after the A hook
+            // levels 4 / 5 (experiments): the shares of level 2 / nothing before the product, rows in need order
+            constexpr int S1 = LV == 5 ? 0 : LV == 3 ? 2 : (LV == 2 || LV == 4) ? 3 : LV == 1 ? 5 : 16; // after the A hook
             constexpr int S2 = LV == 3 ? 4 : S1;                              // after B reads
-            constexpr int S3 = LV == 3 ? 6 : LV == 2 ? 6 : S2;                // after the B hook
-            constexpr int S4 = LV == 3 ? 8 : LV == 2 ? 9 : LV == 1 ? 10 : 16; // after forward
-            constexpr int S5 = LV == 3 ? 10 : LV == 2 ? 11 : S4;              // after the product
-            constexpr int S6 = LV == 3 ? 12 : LV == 2 ? 14 : S5;              // after the C' hook
-            constexpr int S7 = LV == 3 ? 14 : S6;                             // after B' reads
+            constexpr int S3 = LV == 5 ? 0 : LV == 3 ? 6 : (LV == 2 || LV == 4) ? 6 : S2;                // after the B hook
+            constexpr int S4 = LV == 5 ? 4 : LV == 3 ? 8 : (LV == 2 || LV == 4) ? 9 : LV == 1 ? 10 : 16; // after forward
+            constexpr int S5 = LV == 5 ? 8 : LV == 3 ? 10 : (LV == 2 || LV == 4) ? 11 : S4;              // after the product
+            constexpr int S6 = LV == 5 ? 12 : LV == 3 ? 12 : (LV == 2 || LV == 4) ? 14 : S5;              // after the C' hook
+            constexpr int S7 = LV == 5 ? 14 : LV == 3 ? 14 : S6;                             // after B' reads
             auto share = [&](auto lo, auto hi) {
                 if constexpr (!GEN && decltype(lo)::value < decltype(hi)::value) load_rows(pn, nx, lo, hi);
             };
-            forward_tile(v, lds, tid, c, [&] { share(IC<S0>{}, IC<S1>{}); }, after_forward,
+            forward_tile(v, lds, tid, c, [&] { fetch_ticket(); share(IC<S0>{}, IC<S1>{}); }, after_forward,
                          [&] { share(IC<S2>{}, IC<S3>{}); }, [&] { share(IC<S1>{}, IC<S2>{}); });
             share(IC<S3>{}, IC<S4>{});
 #pragma unroll
@@ -571,7 +607,10 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
 #pragma unroll
         for (int n2 = HALO / 256; n2 < 16; ++n2) {
             // a halo that ends inside a row (64 or 128 samples): the row's first waves hold
-            // halo positions and store nothing -- a wave-uniform predicate
+            // halo positions and store nothing -- a wave-uniform predicate.  (One store fewer on
+            // one path makes the compiler's wait at the top of the next tile one operation
+            // stricter than needed on the storing waves; a duplicate store of the next row in
+            // this slot, which evens the counts, measured 0.6 % slower: r02_fft_variants.txt.)
             if (n2 == HALO / 256 && HALO % 256 != 0 && tid < HALO % 256) continue;
             const f2 y = w[P16(n2)];
             if (REAL) {
@@ -581,6 +620,10 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
             } else {
                 stream_store(y, reinterpret_cast<f2*>(q0 + 512 * n2) + tid);
             }
+        }
+        if ((SDR_ABLATE(a) & 1) && !CACHE && ticketed) { // diagnostic builds only: the copy-only loop draws tickets too
+            if (tid == 0) *tbox = ticket;
+            __syncthreads();
         }
         cur = nxt;
         if (!CACHE && ticketed) {
@@ -688,6 +731,9 @@ __device__ __forceinline__ void carry_history(const FftArgs& a, const int w, con
 // instead of trailing it as separate launches.
 template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
 __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftArgs a) {
+    // (padding the LDS to a third of the CU -- which in the copy skeletons moves 4 % more bytes, because 54 KB
+    // workgroups end up TWO per CU and fewer bytes in flight suit the memory system -- costs this kernel 3.5 %:
+    // the transform needs the third workgroup.  profiles/r02_fft_variants.txt)
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
     int bid = blockIdx.x;
     LaneConstsT<TBL> c;
