@@ -470,6 +470,13 @@ def main():
 def run_and_report(args, torch, dist, rank, world, dev, wl):
     """W warm-up steps, K timed steps between barrier + synchronize, max over ranks, one JSON line."""
     step = wl["step"]
+    # Set-up, untimed and not counted as warm-up steps: keep the path running for ~0.2 s so that the GPU has left
+    # its idle clocks before the W warm-up steps begin (the first ~20 launches after idle run 3-5 % slower; a
+    # driver that asks for `--steps 20 --warmup 5` would otherwise time the ramp, not the kernel).
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.2:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
