@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the compile-time knobs this script's libraries were built with (-DSDR_ABL_*, -DSDR_TICKET_MAP, SDR_SPREAD 4/5)
+# were removed from fir_fft.hip once measured; they are in commit 218677c.  -DSDR_FFT_TICKETS and -DSDR_SPREAD=0..3 remain.
 # scripts/exp/chain_ablation.sh -- on the GPU box: what each part of the 4096-point transform pair costs the
 # ticketed persistent loop of fir_fft4096 (diagnostic libraries, garbage results, timing only).
 set -u

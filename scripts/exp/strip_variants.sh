@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the compile-time knobs this script's libraries were built with (-DSDR_ABL_*, -DSDR_TICKET_MAP, SDR_SPREAD 4/5)
+# were removed from fir_fft.hip once measured; they are in commit 218677c.  -DSDR_FFT_TICKETS and -DSDR_SPREAD=0..3 remain.
 # scripts/exp/strip_variants.sh -- on the GPU box: fir_fft4096's loop with the transform stripped (no butterflies,
 # no LDS traffic; barriers, product, tickets, loads and stores stay) under variations of its memory side, next to
 # the copy skeleton (membench10) on the same box.

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the compile-time knobs this script's libraries were built with (-DSDR_ABL_*, -DSDR_TICKET_MAP, SDR_SPREAD 4/5)
+# were removed from fir_fft.hip once measured; they are in commit 218677c.  -DSDR_FFT_TICKETS and -DSDR_SPREAD=0..3 remain.
 # scripts/exp/ticket_variants.sh -- on the GPU box: the ordered-ticket tile hand-out of fir_fft4096 against
 # its variants (diagnostic libraries built by `make -C sdr_amd/csrc diag EXTRA=... DIAG_NAME=...`).
 set -u

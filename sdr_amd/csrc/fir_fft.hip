@@ -48,11 +48,6 @@
 #ifndef SDR_SPREAD
 #define SDR_SPREAD 2
 #endif
-// which ticket counter a workgroup draws from: 0 = bid % FFT_TICKETS (one counter per XCD under round-robin
-// dispatch), 1 = (bid / 8) % FFT_TICKETS (every counter's workgroups spread over all XCDs)
-#ifndef SDR_TICKET_MAP
-#define SDR_TICKET_MAP 0
-#endif
 
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
 // memory pattern.  The release library compiles the switch out.
@@ -61,26 +56,6 @@
 #else
 #define SDR_ABLATE(a) 0
 #endif
-// Experiments only (make diag EXTRA=-DSDR_ABL_NOVALU / -DSDR_ABL_NOLDS / -DSDR_ABL_NOBAR (forward barriers); results are garbage):
-// the transform without its butterflies and twiddles, without its LDS traffic, without its block barriers --
-// what each costs the loop (profiles/r02_fft_chain_ablation.txt).
-#ifdef SDR_ABL_NOVALU
-#define SDR_VALU(x)
-#else
-#define SDR_VALU(x) x
-#endif
-#ifdef SDR_ABL_NOLDS
-#define SDR_LDS(x)
-#else
-#define SDR_LDS(x) x
-#endif
-#define SDR_BAR() __syncthreads()
-#ifdef SDR_ABL_NOBAR
-#define SDR_BARF() // the forward transform's barriers only: the inverse's also publishes the tile ticket
-#else
-#define SDR_BARF() __syncthreads()
-#endif
-
 namespace sdr_amd {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -251,30 +226,30 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW; // this 16-lane group's k0 row
     // ---- A: over n2 -> k0, twiddle W_4096^(r k0) ---------------------------------
-    SDR_VALU(dft16<false>(v));
+    dft16<false>(v);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) SDR_VALU(v[P16(k)] = cmul(v[P16(k)], c.ta(k)));
-    if (after_forward) SDR_BARF();
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.ta(k));
+    if (after_forward) __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) SDR_LDS(lds[k * ROW + tid] = v[P16(k)]);
+    for (int k = 0; k < 16; ++k) lds[k * ROW + tid] = v[P16(k)];
     after_points_left();
-    SDR_BARF();
+    __syncthreads();
     // ---- B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) --------------
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) SDR_LDS(v[n1] = row1[16 * n1 + l16]);
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
     after_b_reads();
-    SDR_VALU(dft16<false>(v));
+    dft16<false>(v);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) SDR_VALU(v[P16(k)] = cmul(v[P16(k)], c.tb(k)));
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.tb(k));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) SDR_LDS(row1[k * 17 + l16] = v[P16(k)]);
+    for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
     after_stage_b();
     __builtin_amdgcn_wave_barrier();
     // ---- C: lane (k0, k1 = l16), over n0 -> k2 ------------------------------------
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) SDR_LDS(v[n0] = row1[l16 * 17 + n0]);
-    SDR_VALU(dft16<false>(v));
+    for (int n0 = 0; n0 < 16; ++n0) v[n0] = row1[l16 * 17 + n0];
+    dft16<false>(v);
 }
 
 // Inverse transform: w[k2] = Y[(tid>>4) + 16 (tid&15) + 256 k2] in (natural k2 order),
@@ -287,30 +262,30 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
     const int l16 = tid & 15;
     f2* row1 = lds + (tid >> 4) * ROW;
     // ---- C': over k2 -> n0 --------------------------------------------------------
-    SDR_VALU(dft16<true>(w));
+    dft16<true>(w);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n0 = 0; n0 < 16; ++n0) SDR_LDS(row1[l16 * 17 + n0] = w[P16(n0)]);
+    for (int n0 = 0; n0 < 16; ++n0) row1[l16 * 17 + n0] = w[P16(n0)];
     after_stage_c();
     __builtin_amdgcn_wave_barrier();
     // ---- B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 ----------------------
 #pragma unroll
-    for (int k = 0; k < 16; ++k) SDR_LDS(w[k] = row1[k * 17 + l16]);
+    for (int k = 0; k < 16; ++k) w[k] = row1[k * 17 + l16];
     after_b_reads();
 #pragma unroll
-    for (int k = 1; k < 16; ++k) SDR_VALU(w[k] = cmulc(w[k], c.tb(k)));
-    SDR_VALU(dft16<true>(w));
+    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.tb(k));
+    dft16<true>(w);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) SDR_LDS(row1[16 * n1 + l16] = w[P16(n1)]);
+    for (int n1 = 0; n1 < 16; ++n1) row1[16 * n1 + l16] = w[P16(n1)];
     before_barrier();
-    SDR_BAR();
+    __syncthreads();
     // ---- A': lane r: conj twiddle, over k0 -> n2 ----------------------------------
 #pragma unroll
-    for (int k = 0; k < 16; ++k) SDR_LDS(w[k] = lds[k * ROW + tid]);
+    for (int k = 0; k < 16; ++k) w[k] = lds[k * ROW + tid];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) SDR_VALU(w[k] = cmulc(w[k], c.ta(k)));
-    SDR_VALU(dft16<true>(w));
+    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.ta(k));
+    dft16<true>(w);
 }
 
 // Filter spectrum of partition p, bin (tid>>4) + 16 (tid&15) + 256 k2, from L2.
@@ -391,14 +366,9 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         const f2* q = reinterpret_cast<const f2*>(p0 + 512 * n2) + tid;
         return again ? *q : stream_load(q);
     };
-    // SDR_SPREAD >= 4: shares are taken in the order the next tile's first butterflies need the rows
-    // (0,4,8,12, 1,5,9,13, ...) instead of 0..15
     auto load_rows = [&](const float* p0, f2 (&dst)[16], auto lo, auto hi) {
 #pragma unroll
-        for (int i = decltype(lo)::value; i < decltype(hi)::value; ++i) {
-            const int n2 = (SDR_SPREAD >= 4 && !LONG) ? 4 * (i & 3) + (i >> 2) : i;
-            dst[n2] = row(p0, n2);
-        }
+        for (int n2 = decltype(lo)::value; n2 < decltype(hi)::value; ++n2) dst[n2] = row(p0, n2);
     };
     auto load = [&](const float* p0, f2 (&dst)[16]) {
 #pragma unroll
@@ -482,7 +452,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     // ~12 ns per ticket, C2 needs one per 11 ns; more counters = looser order = slower).  Flat index g = channel * inner + tile (host: total < 2^31 in this mode).
     const bool ticketed = !CACHE && !runs && a.tickets != nullptr;
     unsigned* const tbox = reinterpret_cast<unsigned*>(lds + (ROW - 1)); // row 0, column 271: no exchange touches it
-    const int tslot = SDR_TICKET_MAP ? (bid / 8) % FFT_TICKETS : bid % FFT_TICKETS;
+    const int tslot = bid % FFT_TICKETS;
     auto pos_of = [&](long long g) -> Pos {
         if (g >= total) return Pos{a.channels, a.t_lo};
         if (a.channels == 1) return Pos{0, a.t_lo + g};
@@ -561,14 +531,13 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
             // after the pointwise product, C' hook, B' reads, before the inverse's barrier).
             constexpr int LV = SPREAD ? SDR_SPREAD : 0;
             constexpr int S0 = 0;
-            // levels 4 / 5 (experiments): the shares of level 2 / nothing before the product, rows in need order
-            constexpr int S1 = LV == 5 ? 0 : LV == 3 ? 2 : (LV == 2 || LV == 4) ? 3 : LV == 1 ? 5 : 16; // after the A hook
+            constexpr int S1 = LV == 3 ? 2 : LV == 2 ? 3 : LV == 1 ? 5 : 16; // after the A hook
             constexpr int S2 = LV == 3 ? 4 : S1;                              // after B reads
-            constexpr int S3 = LV == 5 ? 0 : LV == 3 ? 6 : (LV == 2 || LV == 4) ? 6 : S2;                // after the B hook
-            constexpr int S4 = LV == 5 ? 4 : LV == 3 ? 8 : (LV == 2 || LV == 4) ? 9 : LV == 1 ? 10 : 16; // after forward
-            constexpr int S5 = LV == 5 ? 8 : LV == 3 ? 10 : (LV == 2 || LV == 4) ? 11 : S4;              // after the product
-            constexpr int S6 = LV == 5 ? 12 : LV == 3 ? 12 : (LV == 2 || LV == 4) ? 14 : S5;              // after the C' hook
-            constexpr int S7 = LV == 5 ? 14 : LV == 3 ? 14 : S6;                             // after B' reads
+            constexpr int S3 = LV == 3 ? 6 : LV == 2 ? 6 : S2;                // after the B hook
+            constexpr int S4 = LV == 3 ? 8 : LV == 2 ? 9 : LV == 1 ? 10 : 16; // after forward
+            constexpr int S5 = LV == 3 ? 10 : LV == 2 ? 11 : S4;              // after the product
+            constexpr int S6 = LV == 3 ? 12 : LV == 2 ? 14 : S5;              // after the C' hook
+            constexpr int S7 = LV == 3 ? 14 : S6;                             // after B' reads
             auto share = [&](auto lo, auto hi) {
                 if constexpr (!GEN && decltype(lo)::value < decltype(hi)::value) load_rows(pn, nx, lo, hi);
             };
