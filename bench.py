@@ -99,6 +99,8 @@ def kernel_flops_per_sample(kernel_name, ntaps, cplx, nonzero_taps, gen=False):
     w = 2 if cplx else 1
     if "fft" not in kernel_name:
         return 2.0 * nonzero_taps * w            # one FMA per kept tap per real lane
+    if "pairs" in kernel_name:                   # real samples filtered as complex pairs by the kept taps
+        return kernel_flops_per_sample("fir_fft4096<COMPLEX>", nonzero_taps, True, nonzero_taps, gen) / 2.0
     halo = 64
     while halo + 1 < ntaps and halo < 2048:
         halo *= 2

@@ -64,6 +64,13 @@ struct sdr_fir {
     int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
     float* d_hperm = nullptr;
     const float* d_wtab = nullptr; // twiddle table, stored behind the spectra in d_hperm
+    // Real samples, every other tap zero (the Hilbert design: non-zero taps on the even indices): y[n] depends on
+    // inputs of n's parity only, so the stream IS a complex stream of half the length -- (x[2m], x[2m+1]) -- filtered
+    // by the kept taps.  Calls that allow it (even n and strides, 8-byte aligned buffers) run the complex kernel on
+    // that view: 8-byte accesses instead of 4-byte ones, half the halo, and 2049..4097 such taps need no partitions.
+    bool fft_pair = false;
+    int pair_halo = 0, pair_parts = 1, pair_grid = 0, pair_resident = 0;
+    float* d_hperm_pair = nullptr; // spectra of the kept taps
     unsigned* d_tickets = nullptr; // two sets of tile-ticket counters behind the twiddle table (FftArgs::tickets)
     int tick = 0;                  // the set the next overlap-save launch uses
     int fft_resident = 0;
@@ -228,6 +235,12 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         f->fft_halo = fft_halo;
         f->fft_parts = fft_parts;
         f->hist_len = (fft_parts > 1 ? fft_parts * 2048 : fft_halo) + 4;
+        if (sample_kind == SDR_REAL && stride == 2 && shift == 0 && plan.kept >= 2) {
+            fir_fft_plan(plan.kept, &f->pair_halo, &f->pair_parts);
+            f->fft_pair = true;
+            const int need = 2 * (f->pair_parts > 1 ? f->pair_parts * 2048 : f->pair_halo) + 4; // real samples
+            f->hist_len = std::max(f->hist_len, need); // even either way: both views share the history buffers
+        }
     }
 
     DeviceGuard guard(device);
@@ -265,26 +278,36 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
             sn[m] = std::sin(2.0 * M_PI * m / N);
         }
         // partition p holds taps [p*2048, p*2048+2048) (all taps when parts == 1)
-        const size_t plen = fft_parts > 1 ? 2048 : ntaps;
+        auto spectra = [&](const float* t, size_t nt, int parts, float* dst) {
+            const size_t plen = parts > 1 ? 2048 : nt;
+            for (int p = 0; p < parts; ++p) {
+                const size_t j0 = (size_t)p * plen, j1 = std::min(nt, j0 + plen);
+                for (int k = 0; k < N; ++k) {
+                    double re = 0.0, im = 0.0;
+                    for (size_t j = j0; j < j1; ++j) {
+                        const int m = (int)(((j - j0) * (size_t)k) & (N - 1));
+                        re += t[j] * cs[m];
+                        im -= t[j] * sn[m];
+                    }
+                    const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
+                    const size_t pos = (size_t)p * N + k2 * 256 + 16 * k0 + k1;
+                    dst[2 * pos] = (float)(re / N);
+                    dst[2 * pos + 1] = (float)(im / N);
+                }
+            }
+        };
         std::vector<float> hp((size_t)2 * N * (fft_parts + 1) + FFT_TICKET_WORDS); // spectra, the twiddle table, zeroed ticket counters
         for (int m = 0; m < N; ++m) {
             hp[(size_t)2 * N * fft_parts + 2 * m] = (float)cs[m];
             hp[(size_t)2 * N * fft_parts + 2 * m + 1] = (float)-sn[m];
         }
-        for (int p = 0; p < fft_parts; ++p) {
-            const size_t j0 = (size_t)p * plen, j1 = std::min(ntaps, j0 + plen);
-            for (int k = 0; k < N; ++k) {
-                double re = 0.0, im = 0.0;
-                for (size_t j = j0; j < j1; ++j) {
-                    const int m = (int)(((j - j0) * (size_t)k) & (N - 1));
-                    re += taps[j] * cs[m];
-                    im -= taps[j] * sn[m];
-                }
-                const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
-                const size_t pos = (size_t)p * N + k2 * 256 + 16 * k0 + k1;
-                hp[2 * pos] = (float)(re / N);
-                hp[2 * pos + 1] = (float)(im / N);
-            }
+        spectra(taps, ntaps, fft_parts, hp.data());
+        if (f->fft_pair) {
+            std::vector<float> hq((size_t)2 * N * f->pair_parts);
+            spectra(g.data(), plan.kept, f->pair_parts, hq.data()); // g = the kept taps, in order
+            if ((e = hipMalloc(&f->d_hperm_pair, hq.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
+            if ((e = hipMemcpy(f->d_hperm_pair, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+                return bail(e, "hipMemcpy(spectrum)");
         }
         if ((e = hipMalloc(&f->d_hperm, hp.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
         if ((e = hipMemcpy(f->d_hperm, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
@@ -297,6 +320,8 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         // them leave a shorter tail than two (same-box sweep: 9 per CU 1 % ahead of 6, 12 and 16 level)
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 9);
         f->fft_resident = cus * (fft_parts > 1 ? 2 : 3);
+        f->pair_grid = grid > 0 ? grid : cus * (f->pair_parts > 1 ? 2 : 9);
+        f->pair_resident = cus * (f->pair_parts > 1 ? 2 : 3);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
         f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", grid > 0 ? grid : f->fft_grid));
         f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
@@ -346,6 +371,7 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (f->d_taps) (void)hipFree(f->d_taps);
     if (f->d_atab) (void)hipFree(f->d_atab);
     if (f->d_hperm) (void)hipFree(f->d_hperm);
+    if (f->d_hperm_pair) (void)hipFree(f->d_hperm_pair);
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
     if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -383,21 +409,37 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         fa.in = d_in;
         fa.out = d_out;
         fa.hist = f->d_hist[f->cur];
-        fa.hperm = f->d_hperm;
         fa.wtab = f->d_wtab;
-        fa.n = (long long)n;
-        fa.in_stride = (long long)in_stride;
-        fa.out_stride = (long long)out_stride;
         fa.channels = (long long)f->channels;
-        fa.halo = f->fft_halo;
-        fa.hist_len = f->hist_len;
-        fa.parts = f->fft_parts;
         fa.t_lo = fa.t_hi = 0;
         fa.ablate = f->fft_ablate;
         fa.contig = f->fft_contig;
         fa.new_hist = f->d_hist[f->cur ^ 1];
         take_tickets(f, fa);
-        SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
+        // real samples as complex pairs (see sdr_fir::fft_pair) when this call's shape allows it; either view
+        // leaves the same history behind, so calls of both kinds mix freely
+        const bool pair = f->fft_pair && n % 2 == 0 && ((uintptr_t)d_in % 8 == 0) && ((uintptr_t)d_out % 8 == 0) &&
+                          (f->channels == 1 || (in_stride % 2 == 0 && out_stride % 2 == 0));
+        if (pair) {
+            fa.hperm = f->d_hperm_pair;
+            fa.n = (long long)(n / 2);
+            fa.in_stride = (long long)(in_stride / 2);
+            fa.out_stride = (long long)(out_stride / 2);
+            fa.halo = f->pair_halo;
+            fa.hist_len = f->hist_len / 2;
+            fa.parts = f->pair_parts;
+            fa.resident = env_int("SDR_AMD_FFT_RESIDENT", f->pair_resident);
+            SDR_HIP(launch_fir_fft(fa, false, f->pair_grid, stream));
+        } else {
+            fa.hperm = f->d_hperm;
+            fa.n = (long long)n;
+            fa.in_stride = (long long)in_stride;
+            fa.out_stride = (long long)out_stride;
+            fa.halo = f->fft_halo;
+            fa.hist_len = f->hist_len;
+            fa.parts = f->fft_parts;
+            SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
+        }
         f->cur ^= 1;
         return SDR_OK;
     }
@@ -531,10 +573,11 @@ extern "C" int sdr_fir_reset(sdr_fir_t* f) {
 }
 
 extern "C" size_t sdr_fir_ntaps(const sdr_fir_t* f) { return f ? f->ntaps : 0; }
-extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? (f->use_fft ? 1 : f->k->stride) : 0; }
+extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? (f->use_fft ? (f->fft_pair ? 2 : 1) : f->k->stride) : 0; }
 extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) {
     if (!f) return "";
     if (f->use_mfma) return fir_mfma_kernel_name(f->kind == SDR_REAL, f->k->stride);
+    if (f->use_fft && f->fft_pair) return "fir_fft4096<REAL as complex pairs>";
     return f->use_fft ? fir_fft_kernel_name(f->kind == SDR_REAL) : f->k->name;
 }
 

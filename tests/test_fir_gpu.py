@@ -298,6 +298,42 @@ def test_device_buffers_unaligned_and_strided(cplx):
         assert rel_err(yc, O.fir(taps, x[c])) <= TOL
 
 
+@pytest.mark.parametrize("ntaps", [127, 128, 255, 1003, 4095])
+def test_real_stream_as_complex_pairs(ntaps):
+    """Real samples through a filter whose odd-index taps are zero (the Hilbert design) on the overlap-save
+    path: calls with an even length, even strides and 8-byte aligned buffers run the COMPLEX kernel on the
+    (x[2m], x[2m+1]) view with the kept taps; every other call runs the real kernel.  Both leave the same
+    history, so a stream cut into calls of both kinds -- even, odd, one sample, odd-aligned device pointers,
+    odd channel strides -- must come out as one filter."""
+    import torch
+    rng = np.random.default_rng(ntaps)
+    taps = taps_for("hilbert", ntaps)
+    st = sdr_amd.FirState(taps, False, path="fft")
+    assert "pairs" in st.kernel_name and st.tap_stride == 2, st.kernel_name
+    # (a design whose kept taps sit on the ODD indices -- hilbert(1001): centre tap 500 -- keeps the real kernel)
+    assert "pairs" not in sdr_amd.FirState(taps_for("hilbert", 1001), False, path="fft").kernel_name
+    n = 90001
+    x = rand(rng, n, False)
+    want = O.fir(taps, x)
+    cuts = [0, 30000, 30001, 50002, 50003, 50004, 70004, n]   # even, 1, odd (20001), 1, 1, even, odd
+    y = np.concatenate([sdr_amd.fir(st, x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+    assert rel_err(y, want) <= TOL
+    # device pointers: 8-byte aligned (pair view) and only 4-byte aligned (real view), same stream
+    st.reset()
+    xt = torch.from_numpy(x).cuda()
+    outs = [sdr_amd.fir(st, xt[:40000]), sdr_amd.fir(st, xt[40000:40001]), sdr_amd.fir(st, xt[40001:60001]),
+            sdr_amd.fir(st, xt[60001:])]
+    y2 = torch.cat(outs).cpu().numpy()
+    assert rel_err(y2, want) <= TOL
+    # channels: even stride (pair view) and odd stride (real view)
+    C = 3
+    xc = np.stack([rand(rng, 20001, False) for _ in range(C)])
+    stc = sdr_amd.FirState(taps, False, channels=C, path="fft")
+    yc = np.concatenate([sdr_amd.fir(stc, xc[:, :12000]), sdr_amd.fir(stc, xc[:, 12000:])], axis=1)
+    for c in range(C):
+        assert rel_err(yc[c], O.fir(taps, xc[c])) <= TOL, c
+
+
 def test_linearity_and_impulse_full_size():
     """Config C2 size (2^28 complex samples, 127-tap lowpass) through
     size-independent properties: impulse response = taps at the impulse
