@@ -172,37 +172,28 @@ struct LaneConstsT {
         else return TB[k];
     }
     __device__ __forceinline__ f2 ta(int k) const { return TA[k]; }
-    // wtab = exp(-2 pi i m / 4096), m = 0..4095, computed once per filter on the host
-    // (double, rounded to fp32).  A workgroup copies it into the exchange buffer `stage`
-    // (>= 4096 entries) with 16 coalesced loads per lane and picks its twiddles out of LDS:
-    // 32 KB of L2 traffic and no sincos evaluation (30 of them per lane cost three tiles'
-    // worth of arithmetic -- most of a short call).  `table`: 256 entries for TBL.
+    // wtab: the per-lane twiddles, laid out by the host (double, rounded to fp32) exactly as the lanes take
+    // them: wtab[256 k + tid] = W_4096^(tid k) for k = 0..15, then 256 entries W_256^(n k) at [4096 + 16 k + n].
+    // 15 coalesced loads per lane (L2-hot: every workgroup reads the same 34 KB) and one LDS write; no
+    // staging through the exchange buffer and no barrier of its own -- the 256-entry table is first read in
+    // stage B of a forward transform, behind that transform's block barrier.  (Round 1 copied a 4096-entry
+    // exp table into LDS and gathered from it: two barriers and 30 conflicting LDS reads per workgroup, a
+    // quarter of a C1-sized call.)  `stage` is unused; `table`: 256 entries for TBL.
     __device__ __forceinline__ void init(int tid, const float* hperm, bool with_spectrum, const f2* wtab, f2* stage,
                                          f2* table = nullptr) {
+        (void)stage;
         tb_lds = nullptr;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) stage[256 * k + tid] = wtab[256 * k + tid];
-        __syncthreads();
-#pragma unroll
-        for (int k = 1; k < 16; ++k) TA[k] = stage[(tid * k) & 4095];
+        for (int k = 1; k < 16; ++k) TA[k] = wtab[256 * k + tid];
         if constexpr (TBL) {
             // table[16 k + n] = W_256^(n k); a lane reads column n = tid & 15 (broadcast within 16-lane groups)
-            table[tid] = stage[16 * (((tid & 15) * (tid >> 4)) & 255)];
+            table[tid] = wtab[4096 + tid];
             tb_lds = table + (tid & 15);
         } else {
             (void)table;
 #pragma unroll
-            for (int k = 1; k < 16; ++k) TB[k] = stage[16 * (((tid & 15) * k) & 255)];
+            for (int k = 1; k < 16; ++k) TB[k] = wtab[4096 + 16 * k + (tid & 15)];
         }
-        // Pin the LDS reads above ahead of the barrier: left alone, the compiler sinks them
-        // below it (a plain load may move past an acquire), to where other waves are already
-        // writing their first tile into the exchange buffer.
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            asm volatile("" : "+v"(TA[k].x), "+v"(TA[k].y));
-            if constexpr (!TBL) asm volatile("" : "+v"(TB[k].x), "+v"(TB[k].y));
-        }
-        __syncthreads(); // the exchange buffer is free again; the table is published
         if (with_spectrum) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) H[k] = reinterpret_cast<const f2*>(hperm)[k * 256 + tid];

@@ -38,7 +38,7 @@ struct FftArgs {
     float* out;
     const float* hist;    // [channels][hist_len]
     const float* hperm;   // parts x 4096 complex: H_p[k]/N stored at [p*4096 + k2*256 + 16*k0 + k1], k = k0 + 16 k1 + 256 k2
-    const float* wtab;    // 4096 complex: exp(-2 pi i m / 4096)
+    const float* wtab;    // 4096 + 256 complex: W_4096^(tid k) at [256 k + tid], W_256^(n k) at [4096 + 16 k + n]
     long long n;
     long long in_stride;
     long long out_stride;

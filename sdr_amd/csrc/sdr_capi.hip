@@ -63,7 +63,7 @@ struct sdr_fir {
     int fft_grid = 0;
     int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
     float* d_hperm = nullptr;
-    const float* d_wtab = nullptr; // twiddle table, stored behind the spectra in d_hperm
+    const float* d_wtab = nullptr; // per-lane twiddle tables, stored behind the spectra in d_hperm
     // Real samples, every other tap zero (the Hilbert design: non-zero taps on the even indices): y[n] depends on
     // inputs of n's parity only, so the stream IS a complex stream of half the length -- (x[2m], x[2m+1]) -- filtered
     // by the kept taps.  Calls that allow it (even n and strides, 8-byte aligned buffers) run the complex kernel on
@@ -296,10 +296,24 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
                 }
             }
         };
-        std::vector<float> hp((size_t)2 * N * (fft_parts + 1) + FFT_TICKET_WORDS); // spectra, the twiddle table, zeroed ticket counters
-        for (int m = 0; m < N; ++m) {
-            hp[(size_t)2 * N * fft_parts + 2 * m] = (float)cs[m];
-            hp[(size_t)2 * N * fft_parts + 2 * m + 1] = (float)-sn[m];
+        // spectra, the per-lane twiddle tables (LaneConstsT::init: W_4096^(tid k) at [256 k + tid], W_256^(n k) at
+        // [4096 + 16 k + n]), zeroed ticket counters
+        constexpr size_t TW = 4096 + 256;
+        std::vector<float> hp((size_t)2 * N * fft_parts + 2 * TW + FFT_TICKET_WORDS);
+        {
+            float* tw = hp.data() + (size_t)2 * N * fft_parts;
+            for (int k = 0; k < 16; ++k)
+                for (int t = 0; t < 256; ++t) {
+                    const int m = (t * k) & (N - 1);
+                    tw[2 * (256 * k + t)] = (float)cs[m];
+                    tw[2 * (256 * k + t) + 1] = (float)-sn[m];
+                }
+            for (int k = 0; k < 16; ++k)
+                for (int n0 = 0; n0 < 16; ++n0) {
+                    const int m = 16 * ((n0 * k) & 255);
+                    tw[2 * (4096 + 16 * k + n0)] = (float)cs[m];
+                    tw[2 * (4096 + 16 * k + n0) + 1] = (float)-sn[m];
+                }
         }
         spectra(taps, ntaps, fft_parts, hp.data());
         if (f->fft_pair) {
@@ -313,7 +327,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         if ((e = hipMemcpy(f->d_hperm, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
             return bail(e, "hipMemcpy(spectrum)");
         f->d_wtab = f->d_hperm + (size_t)2 * N * fft_parts;
-        f->d_tickets = reinterpret_cast<unsigned*>(f->d_hperm + (size_t)2 * N * (fft_parts + 1));
+        f->d_tickets = reinterpret_cast<unsigned*>(f->d_hperm + (size_t)2 * N * fft_parts + 2 * TW);
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         // three workgroups are resident per CU (two for the partitioned variants); three rounds of
