@@ -48,6 +48,11 @@
 #ifndef SDR_SPREAD
 #define SDR_SPREAD 2
 #endif
+// spectrum-cache variant: the second partition's spectrum in LDS (1) or read from L2 per tile (0: experiments;
+// same box C3 0.415 / 0.425 ms, real samples 0.394 / 0.420)
+#ifndef SDR_CACHE_H1_LDS
+#define SDR_CACHE_H1_LDS 1
+#endif
 
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
 // memory pattern.  The release library compiles the switch out.
@@ -471,6 +476,10 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     // the lane constants are set up with the first tile's loads already in flight (every
     // lane of the workgroup gets here or none does: the returns above are uniform)
     c.init(tid, a.hperm, !LONG, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
+    if constexpr (CACHE && SDR_CACHE_H1_LDS) { // each lane reads back only what it wrote itself: no barrier needed
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[16 * ROW + 256 + 256 * k + tid] = spectrum(a.hperm, 1, k, tid);
+    }
 
     auto body = [&]() {
         f2 v[16];
@@ -540,7 +549,8 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
             if (CACHE) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    w[k] += cmul(prev[CACHE ? k : 0], spectrum(a.hperm, 1, k, tid));
+                    const f2 h1 = SDR_CACHE_H1_LDS ? lds[16 * ROW + 256 + 256 * k + tid] : spectrum(a.hperm, 1, k, tid);
+                    w[k] += cmul(prev[CACHE ? k : 0], h1);
                     prev[CACHE ? k : 0] = v[P16(k)];
                 }
             }
@@ -694,7 +704,9 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     // (padding the LDS to a third of the CU -- which in the copy skeletons moves 4 % more bytes, because 54 KB
     // workgroups end up TWO per CU and fewer bytes in flight suit the memory system -- costs this kernel 3.5 %:
     // the transform needs the third workgroup.  profiles/r02_fft_variants.txt)
-    __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0)];
+    // CACHE: the second partition's spectrum lives in LDS (32 KB more: two workgroups per CU still fit), copied
+    // once per workgroup -- the product then waits on 16 L2 loads and 16 LDS reads instead of 32 L2 loads
+    __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0) + ((CACHE && SDR_CACHE_H1_LDS) ? 4096 : 0)];
     int bid = blockIdx.x;
     LaneConstsT<TBL> c;
     if (!LONG && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
