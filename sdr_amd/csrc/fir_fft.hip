@@ -50,6 +50,11 @@
 #endif
 // spectrum-cache variant: the second partition's spectrum in LDS (1) or read from L2 per tile (0: experiments;
 // same box C3 0.415 / 0.425 ms, real samples 0.394 / 0.420)
+// spectrum-cache variant: the next tile's loads in shares like the single-spectrum variants (1) or in one burst (0).
+// With its second spectrum in LDS the kernel has the registers for it: C3 0.418 -> 0.396 ms (level 2; 1: 0.404, 3: 0.399)
+#ifndef SDR_CACHE_SPREAD
+#define SDR_CACHE_SPREAD 1
+#endif
 #ifndef SDR_CACHE_H1_LDS
 #define SDR_CACHE_H1_LDS 1
 #endif
@@ -316,7 +321,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
     static_assert(!GEN || REAL, "the generator source produces real samples");
     const int tid = threadIdx.x;
-    constexpr bool SPREAD = !LONG && SDR_SPREAD; // single-spectrum variants: spread the prefetch (see the main loop)
+    constexpr bool SPREAD = (!LONG || (CACHE && SDR_CACHE_SPREAD)) && SDR_SPREAD; // single-spectrum variants: spread the prefetch (see the main loop)
     constexpr int W = REAL ? 1 : 2;
     constexpr int HALO = 64 * HQ;
     constexpr long long L = FFT_N - HALO;
