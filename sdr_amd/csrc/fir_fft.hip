@@ -55,6 +55,12 @@
 #ifndef SDR_CACHE_SPREAD
 #define SDR_CACHE_SPREAD 1
 #endif
+// spectrum-cache variant: carry and edge workgroups lead the main launch (1) like in the single-spectrum variants, or
+// run as a launch of their own behind it (0).  Round 1 measured the shared kernel 20 % slower (its main loop was
+// scheduled worse at 252 VGPRs); at 200 it is 1.5-2.5 % faster than two launches (C3 0.390 / 0.395 ms).
+#ifndef SDR_CACHE_ONE_LAUNCH
+#define SDR_CACHE_ONE_LAUNCH 1
+#endif
 #ifndef SDR_CACHE_H1_LDS
 #define SDR_CACHE_H1_LDS 1
 #endif
@@ -714,10 +720,10 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0) + ((CACHE && SDR_CACHE_H1_LDS) ? 4096 : 0)];
     int bid = blockIdx.x;
     LaneConstsT<TBL> c;
-    if (!LONG && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
-    // (the partitioned variants keep their short work in a launch of its own,
-    // fir_fft4096_short: sharing a kernel with it costs their main loop 20 %)
-    if constexpr (!LONG) {
+    constexpr bool ONE_LAUNCH = !LONG || (CACHE && SDR_CACHE_ONE_LAUNCH);
+    if (ONE_LAUNCH && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
+    // (the uncached partitioned variants keep their short work in a launch of its own, fir_fft4096_short)
+    if constexpr (ONE_LAUNCH) {
         if (bid < a.grid_carry) {
             carry_history<GEN>(a, REAL ? 1 : 2, bid, a.grid_carry);
             return;
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
         bid -= a.grid_edge;
     }
     interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
-                                                    LONG ? (int)gridDim.x : (int)gridDim.x - a.grid_carry - a.grid_edge);
+                                                    ONE_LAUNCH ? (int)gridDim.x - a.grid_carry - a.grid_edge : (int)gridDim.x);
 }
 
 // carry + edge workgroups alone (partitioned filters; calls without interior tiles)
@@ -755,6 +761,10 @@ template <bool REAL, bool GEN>
 static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t stream) {
     const dim3 b(256);
     const int n_short = a.grid_carry + a.grid_edge;
+    if (a.parts == 2 && SDR_CACHE_ONE_LAUNCH && !(SDR_ABLATE(a) & 4)) {
+        hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, true, true, GEN>), dim3((unsigned)(grid_int + n_short)), b, 0, stream, a);
+        return hipGetLastError();
+    }
     if (a.parts > 1) {
         const dim3 g((unsigned)grid_int);
         if (grid_int > 0) {
