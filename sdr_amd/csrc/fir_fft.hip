@@ -61,6 +61,11 @@
 #ifndef SDR_CACHE_ONE_LAUNCH
 #define SDR_CACHE_ONE_LAUNCH 1
 #endif
+// spectrum-cache variant: W_256 twiddles in registers (0) or read from the LDS table (1).  At two workgroups per CU
+// the kernel has the 27 registers, and 30 fewer LDS reads per tile are worth 2 % (C3 0.384 / 0.391 ms).
+#ifndef SDR_CACHE_TBL
+#define SDR_CACHE_TBL 0
+#endif
 #ifndef SDR_CACHE_H1_LDS
 #define SDR_CACHE_H1_LDS 1
 #endif
@@ -489,7 +494,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     c.init(tid, a.hperm, !LONG, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
     if constexpr (CACHE && SDR_CACHE_H1_LDS) { // each lane reads back only what it wrote itself: no barrier needed
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds[16 * ROW + 256 + 256 * k + tid] = spectrum(a.hperm, 1, k, tid);
+        for (int k = 0; k < 16; ++k) lds[16 * ROW + (TBL ? 256 : 0) + 256 * k + tid] = spectrum(a.hperm, 1, k, tid);
     }
 
     auto body = [&]() {
@@ -560,7 +565,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
             if (CACHE) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const f2 h1 = SDR_CACHE_H1_LDS ? lds[16 * ROW + 256 + 256 * k + tid] : spectrum(a.hperm, 1, k, tid);
+                    const f2 h1 = SDR_CACHE_H1_LDS ? lds[16 * ROW + (TBL ? 256 : 0) + 256 * k + tid] : spectrum(a.hperm, 1, k, tid);
                     w[k] += cmul(prev[CACHE ? k : 0], h1);
                     prev[CACHE ? k : 0] = v[P16(k)];
                 }
@@ -762,7 +767,7 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
     const dim3 b(256);
     const int n_short = a.grid_carry + a.grid_edge;
     if (a.parts == 2 && SDR_CACHE_ONE_LAUNCH && !(SDR_ABLATE(a) & 4)) {
-        hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, true, true, GEN>), dim3((unsigned)(grid_int + n_short)), b, 0, stream, a);
+        hipLaunchKernelGGL((fir_fft4096<REAL, 32, true, SDR_CACHE_TBL != 0, true, GEN>), dim3((unsigned)(grid_int + n_short)), b, 0, stream, a);
         return hipGetLastError();
     }
     if (a.parts > 1) {
