@@ -48,26 +48,27 @@
 #ifndef SDR_SPREAD
 #define SDR_SPREAD 2
 #endif
-// spectrum-cache variant: the second partition's spectrum in LDS (1) or read from L2 per tile (0: experiments;
-// same box C3 0.415 / 0.425 ms, real samples 0.394 / 0.420)
-// spectrum-cache variant: the next tile's loads in shares like the single-spectrum variants (1) or in one burst (0).
+// Four choices of the spectrum-cache variant (C3), each measured against its alternative on the same box
+// (profiles/r02_fft_variants.txt).  The second partition's spectrum in LDS (1) or read from L2 per tile (0):
+// C3 0.415 / 0.425 ms, real samples 0.394 / 0.420.
+#ifndef SDR_CACHE_H1_LDS
+#define SDR_CACHE_H1_LDS 1
+#endif
+// the next tile's loads in shares like the single-spectrum variants (1) or in one burst (0).
 // With its second spectrum in LDS the kernel has the registers for it: C3 0.418 -> 0.396 ms (level 2; 1: 0.404, 3: 0.399)
 #ifndef SDR_CACHE_SPREAD
 #define SDR_CACHE_SPREAD 1
 #endif
-// spectrum-cache variant: carry and edge workgroups lead the main launch (1) like in the single-spectrum variants, or
+// carry and edge workgroups lead the main launch (1) like in the single-spectrum variants, or
 // run as a launch of their own behind it (0).  Round 1 measured the shared kernel 20 % slower (its main loop was
 // scheduled worse at 252 VGPRs); at 200 it is 1.5-2.5 % faster than two launches (C3 0.390 / 0.395 ms).
 #ifndef SDR_CACHE_ONE_LAUNCH
 #define SDR_CACHE_ONE_LAUNCH 1
 #endif
-// spectrum-cache variant: W_256 twiddles in registers (0) or read from the LDS table (1).  At two workgroups per CU
+// W_256 twiddles in registers (0) or read from the LDS table (1).  At two workgroups per CU
 // the kernel has the 27 registers, and 30 fewer LDS reads per tile are worth 2 % (C3 0.384 / 0.391 ms).
 #ifndef SDR_CACHE_TBL
 #define SDR_CACHE_TBL 0
-#endif
-#ifndef SDR_CACHE_H1_LDS
-#define SDR_CACHE_H1_LDS 1
 #endif
 
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
