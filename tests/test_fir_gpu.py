@@ -402,6 +402,38 @@ def test_non_finite_sample_stays_local(path, ntaps, reach, bad):
     assert rel_err(y[keep], want[keep]) <= TOL
 
 
+@pytest.mark.parametrize("kind,ntaps,cplx", [("lowpass", 127, True), ("hilbert", 127, False), ("lowpass", 31, True),
+                                             ("lowpass", 15, False), ("bandpass", 4095, True)])
+def test_hip_graph_of_two_calls_replays_as_a_stream(kind, ntaps, cplx):
+    """a handle keeps its history (and the overlap-save kernels their tile tickets) in two
+    buffers that swap roles on every call, so a captured HIP graph must hold an EVEN number of calls.  Two
+    device calls captured once and replayed three times filter six consecutive chunks as one stream; nothing
+    in the device entry point allocates or synchronises, so the capture itself must succeed."""
+    import torch
+    rng = np.random.default_rng(ntaps + cplx)
+    taps = taps_for(kind, ntaps)
+    n, reps = 30000, 3
+    x = rand(rng, 2 * n * reps, cplx)
+    st = sdr_amd.FirState(taps, cplx)
+    shape = (2 * n, 2) if cplx else (2 * n,)
+    d_in = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    d_out = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        st.process_tensor(d_in[:n], d_out[:n])
+        st.process_tensor(d_in[n:], d_out[n:])
+    got = []
+    for r in range(reps):
+        chunk = x[2 * n * r:2 * n * (r + 1)]
+        d_in.copy_(torch.from_numpy(chunk.view(np.float32).reshape(shape)))
+        graph.replay()
+        torch.cuda.synchronize()
+        o = d_out.cpu().numpy()
+        got.append(o.reshape(-1).view(np.complex64) if cplx else o.reshape(-1))
+    assert rel_err(np.concatenate(got), O.fir(taps, x)) <= TOL
+
+
 def test_in_place_is_refused():
     """Tiles re-read their neighbours' inputs: the ABI says in and out must not overlap, and
     the library checks rather than filter its own outputs."""
