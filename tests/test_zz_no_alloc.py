@@ -85,3 +85,34 @@ def test_no_alloc_limits():
         sdr_amd.fir_apply_device_noalloc(np.ones(5, np.float32), False, xd.data_ptr(), (1 << 36) + 1, yd.data_ptr())
     with pytest.raises(sdr_amd.SdrError):   # in and out overlap
         sdr_amd.fir_apply_device_noalloc(np.ones(5, np.float32), False, xd.data_ptr(), 1000, xd.data_ptr() + 400)
+
+
+def test_no_alloc_under_hip_graph_capture():
+    """One of the callers the entry point is for: code under HIP graph capture.  After one ordinary call on
+    the device (which takes the scratch array's address), a call captured into a graph and replayed on new
+    input gives the same bytes as the ordinary call."""
+    import torch
+    taps = sdr_amd.fir_lowpass(63, 0.2)
+    rng = np.random.default_rng(9)
+    n = 40000
+    xd = torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)).cuda()
+    yd = torch.empty_like(xd)
+    sdr_amd.fir_apply_device_noalloc(taps, False, xd.data_ptr(), n, yd.data_ptr(),
+                                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    gd = torch.empty_like(xd)
+    with torch.cuda.graph(graph, stream=side):
+        sdr_amd.fir_apply_device_noalloc(taps, False, xd.data_ptr(), n, gd.data_ptr(),
+                                         stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        xd.copy_(torch.from_numpy(x))
+        graph.replay()
+        sdr_amd.fir_apply_device_noalloc(taps, False, xd.data_ptr(), n, yd.data_ptr(),
+                                         stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(gd.cpu().numpy(), yd.cpu().numpy())
+        ref = O.fir(taps, x)
+        assert np.max(np.abs(gd.cpu().numpy() - ref)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2)) <= TOL
