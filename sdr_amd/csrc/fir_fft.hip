@@ -388,64 +388,92 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         for (int n2 = 0; n2 < 16; ++n2) dst[n2] = row(p0, n2);
     };
     // GEN: the pair (x[o + 256 n2 + tid], x[o + D + 256 n2 + tid]) for n2 = 0..15 (o >= 0,
-    // wave-uniform).  A row of 256 consecutive samples touches at most two generator
-    // blocks (B >= 256): both phases come through scalar loads, the lane picks one.
-    struct Cursor { long long b; int rb; }; // block and in-block offset of a row's first sample
+    // wave-uniform).  Every lane walks its own two samples down the 16 rows: in-block index
+    // (a float: exact integers below 2^24) and start phase of its block.  A row step adds 256
+    // to the index; a lane that runs off its block (B >= 256: at most once per step) moves to
+    // the next block's phase by the host's own recurrence (sdr_capi.hip gen_next_table: one
+    // fp32 addition, one conditional subtraction -- the same bits as the table's next entry),
+    // so the walk touches no memory: only the two phases at its start come from the table.
+    // With the usual B of a few thousand samples a wave wraps every B/256 rows: the row step
+    // is one packed add and two compares ahead of a wave-uniform branch.  (r01 kept scalar
+    // cursors per row and picked phases per lane: 43 VALU instructions per sample, 0.963 ms
+    // for C5; profiles/r02_fft_variants.txt.)
+    struct Walk { float idx, p, base; };    // base = p (+ 0.25 for cosine): what the sample formula takes
+    struct Cursor { long long b; int rb; }; // block and in-block offset of a sample
+    const int genB = GEN ? (int)a.gen.block_size : 1;
+    const float genBf = (float)genB;
+    const float gen_quarter = GEN && a.gen.waveform == 0 ? 0.25f : 0.0f;
     auto cursor_at = [&](long long o) {
-        const int B = (int)a.gen.block_size;
         long long b = (long long)((double)o * a.gen.inv_block);
-        long long r = o - b * B;
-        if (r < 0) { r += B; --b; }
-        else if (r >= B) { r -= B; ++b; }
+        long long r = o - b * genB;
+        if (r < 0) { r += genB; --b; }
+        else if (r >= genB) { r -= genB; ++b; }
         return Cursor{b, (int)r};
     };
-    auto synth = [&](long long o, f2 (&dst)[16]) {
-        const int B = (int)a.gen.block_size;
-        Cursor c0 = cursor_at(o), c1 = cursor_at(o + D);
-        auto next_row = [&](Cursor& c) {
-            c.rb += 256;
-            if (c.rb >= B) { c.rb -= B; ++c.b; }
-        };
-        if (a.gen.waveform <= 1) {
-            // sine / cosine: straight-line polynomial on both members at once; the lane's
-            // in-block index is formed in float (tid + row offset: exact small integers)
-            const float tidf = (float)tid;
-            auto lane = [&](const Cursor& c, float& idx) {
-                const float pa = a.gen.phi[c.b], pb = a.gen.phi[c.b + 1];
-                const bool wrap = tid >= B - c.rb;
-                idx = tidf + (wrap ? (float)(c.rb - B) : (float)c.rb);
-                return wrap ? pb : pa;
-            };
-#pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) {
-                float i0, i1;
-                const float p0 = lane(c0, i0), p1 = lane(c1, i1);
-                dst[n2] = gen_sine_pair(a.gen.amp, a.gen.cps, f2{p0, p1}, f2{i0, i1});
-                next_row(c0);
-                next_row(c1);
-            }
-        } else {
-            auto lane = [&](const Cursor& c, int& i) { // in-block index and start phase of this lane's sample
-                const float pa = a.gen.phi[c.b], pb = a.gen.phi[c.b + 1];
-                i = c.rb + tid;
-                const bool wrap = i >= B;
-                i = wrap ? i - B : i;
-                return wrap ? pb : pa;
-            };
-#pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) {
-                int i0, i1;
-                const float p0 = lane(c0, i0), p1 = lane(c1, i1);
-                dst[n2] = f2{gen_real_sample(a.gen.waveform, a.gen.amp, a.gen.cps, p0, i0),
-                             gen_real_sample(a.gen.waveform, a.gen.amp, a.gen.cps, p1, i1)};
-                next_row(c0);
-                next_row(c1);
-            }
+    const Cursor genD = GEN ? cursor_at(D) : Cursor{0, 0}; // the im member runs D samples ahead of the re member
+    auto walk_open = [&](Cursor c, Walk& s) __attribute__((always_inline)) {
+        int i = c.rb + tid;
+        const bool wrap = i >= genB;
+        i = wrap ? i - genB : i;
+        s.idx = (float)i;
+        s.p = a.gen.phi[(unsigned)c.b + (wrap ? 1u : 0u)];
+        s.base = s.p + gen_quarter;
+    };
+    auto gen_open = [&](long long o, Walk& s0, Walk& s1) __attribute__((always_inline)) {
+        const Cursor c0 = cursor_at(o);
+        Cursor c1{c0.b + genD.b, c0.rb + genD.rb};
+        if (c1.rb >= genB) { c1.rb -= genB; ++c1.b; }
+        walk_open(c0, s0);
+        walk_open(c1, s1);
+    };
+    auto walk_wrap = [&](Walk& s, bool wrap) __attribute__((always_inline)) {
+        if (wrap) {
+            s.idx -= genBf;
+            const float t = s.p + a.gen.phi_incr; // both in [0, 1], 1 only where a fract() rounded up
+            s.p = t >= 1.0f ? t - 1.0f : t;
+            s.p = s.p >= 1.0f ? s.p - 1.0f : s.p;
+            s.base = s.p + gen_quarter;
         }
+    };
+    // rows [LO, HI) of a window; the walkers stand at row LO - 1 (LO > 0) or at row 0 and are left at row HI - 1.
+    // (Variants that cost more instructions on the common path, for the copies with which the compiler merges the
+    // two paths of a step: both members in one vector-typed walker, the wrap written with selects, a wave-uniform
+    // skip per member, a block of its own for the common path: 28-32 instructions per row where this form has 27.)
+    auto gen_rows_of = [&](auto sine, Walk& s0, Walk& s1, f2 (&dst)[16], auto lo, auto hi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n2 = decltype(lo)::value; n2 < decltype(hi)::value; ++n2) {
+            if (n2 > 0) {
+                s0.idx += 256.0f;
+                s1.idx += 256.0f;
+                const bool w0 = s0.idx >= genBf, w1 = s1.idx >= genBf;
+                if (__any(w0 || w1)) {
+                    walk_wrap(s0, w0);
+                    walk_wrap(s1, w1);
+                }
+            }
+            if constexpr (decltype(sine)::value) { // straight-line polynomial on both members at once
+                dst[n2] = gen_sine_pair(a.gen.amp, a.gen.cps, f2{s0.base, s1.base}, f2{s0.idx, s1.idx});
+            } else {
+                dst[n2] = f2{gen_real_sample_f(a.gen.waveform, a.gen.amp, a.gen.cps, s0.p, s0.idx),
+                             gen_real_sample_f(a.gen.waveform, a.gen.amp, a.gen.cps, s1.p, s1.idx)};
+            }
+            // the row's samples are computed before the walk moves on (the compiler otherwise sinks all
+            // sixteen evaluations below the fifteen steps and copies every row's phase and index aside)
+            asm volatile("" : "+v"(s0.idx), "+v"(s1.idx) : "v"(dst[n2]));
+        }
+    };
+    auto gen_rows = [&](Walk& s0, Walk& s1, f2 (&dst)[16], auto lo, auto hi) __attribute__((always_inline)) {
+        if (a.gen.waveform <= 1) gen_rows_of(IC<1>{}, s0, s1, dst, lo, hi);
+        else gen_rows_of(IC<0>{}, s0, s1, dst, lo, hi);
+    };
+    auto synth = [&](long long o, f2 (&dst)[16]) __attribute__((always_inline)) {
+        Walk s0, s1;
+        gen_open(o, s0, s1);
+        gen_rows(s0, s1, dst, IC<0>{}, IC<16>{});
     };
     // the tile's 4096-point window, `back` samples earlier (previous windows of the
     // partitioned mode): loaded, or synthesised
-    auto fetch = [&](Pos p, long long back, f2 (&dst)[16]) {
+    auto fetch = [&](Pos p, long long back, f2 (&dst)[16]) __attribute__((always_inline)) {
         if constexpr (GEN) {
             synth(first_out(p) - HALO - back, dst);
         } else {
@@ -488,8 +516,13 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         while (cur.tt >= a.t_hi) { cur.tt -= inner; ++cur.ch; }
     }
     Pos nxt = advance(cur); // the tile after `cur`; past the last one: ch >= channels (runs: see `left`)
-    f2 nx[GEN ? 1 : 16]; // the next tile's points, loaded one tile ahead (nothing to prefetch with GEN)
-    if constexpr (!GEN) load(in_ptr(cur), nx);
+    f2 nx[GEN ? 1 : 16]; // the next tile's points, loaded one tile ahead
+    // GEN: the next tile's walkers instead -- their two phases are what comes from memory.  (Synthesising the
+    // next tile's points in the prefetch shares as well, between the transform's phases, measured 3 % slower
+    // than synthesising a tile's points at its top: profiles/r02_fft_variants.txt.)
+    Walk g0{}, g1{};
+    if constexpr (GEN) gen_open(first_out(cur) - HALO, g0, g1);
+    else load(in_ptr(cur), nx);
     // the lane constants are set up with the first tile's loads already in flight (every
     // lane of the workgroup gets here or none does: the returns above are uniform)
     c.init(tid, a.hperm, !LONG, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
@@ -498,7 +531,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         for (int k = 0; k < 16; ++k) lds[16 * ROW + (TBL ? 256 : 0) + 256 * k + tid] = spectrum(a.hperm, 1, k, tid);
     }
 
-    auto body = [&]() {
+    auto body = [&]() __attribute__((always_inline)) {
         f2 v[16];
         bool after_forward = false;
         // The ticket for the tile after next: one atomic by lane 0, issued once the prefetched points have left
@@ -522,7 +555,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
             after_forward = true;
         }
         if constexpr (GEN) {
-            fetch(cur, 0, v);
+            gen_rows(g0, g1, v, IC<0>{}, IC<16>{});
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = nx[GEN ? 0 : i];
@@ -534,6 +567,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         Pos pf = nxt;
         if (runs ? left <= 1 : nxt.ch >= a.channels) pf = Pos{0, a.t_lo};
         const float* pn = in_ptr(pf);
+        if constexpr (GEN) gen_open(first_out(pf) - HALO, g0, g1);
         f2 w[16];
         if (SDR_ABLATE(a) & 1) {
             fetch_ticket();

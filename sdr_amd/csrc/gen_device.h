@@ -19,8 +19,8 @@ namespace sdr_amd {
 
 // Generator as an input source of a FIR kernel (real samples only).
 struct GenSrc {
-    const float* phi;     // start phase of blocks 0..blocks of this call (one spare entry at the end);
-                          // cosine: already advanced by the quarter cycle (phi + 0.25f)
+    const float* phi;     // start phase of blocks 0..blocks of this call (one spare entry at the end)
+    float phi_incr;       // phase advance per block, in [0, 1): phi[k+1] = phi[k] + phi_incr, less 1 if >= 1 (fp32)
     long long block_size; // B, 256 <= B <= 2^23
     double inv_block;     // 1.0 / B
     float amp;
@@ -87,12 +87,16 @@ __device__ __forceinline__ float wave_real(int waveform, float arg) {
 }
 
 // One real sample of block phase `phi`, in-block index i (blocks/gen.cpp:183-195).
-__device__ __forceinline__ float gen_real_sample(int waveform, float amp, float cps, float phi, int i) {
+// The in-block index arrives as a float (an exact integer below 2^24).
+__device__ __forceinline__ float gen_real_sample_f(int waveform, float amp, float cps, float phi, float i) {
 #pragma clang fp contract(off)
     const float base = waveform == 0 ? phi + 0.25f : phi;
-    const float step = cps * (float)i;
+    const float step = cps * i;
     const float arg = base + step;
     return amp * wave_real(waveform, arg);
+}
+__device__ __forceinline__ float gen_real_sample(int waveform, float amp, float cps, float phi, int i) {
+    return gen_real_sample_f(waveform, amp, cps, phi, (float)i);
 }
 
 // Same for sine / cosine only: `base` = phi (+0.25 for cosine), no waveform dispatch.
@@ -146,7 +150,6 @@ __device__ __forceinline__ float gen_src_at(const GenSrc& g, long long m) {
     long long r = m - b * g.block_size;
     if (r < 0) { r += g.block_size; --b; }
     else if (r >= g.block_size) { r -= g.block_size; ++b; }
-    if (g.waveform == 0) return gen_sine_sample(g.amp, g.cps, g.phi[b], (int)r); // table holds phi + 0.25
     return gen_real_sample(g.waveform, g.amp, g.cps, g.phi[b], (int)r);
 }
 

@@ -721,11 +721,9 @@ extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
 // The next `blocks` per-block start phases (plus one spare entry, read but never used
 // by kernels that look one block ahead) into the next table of the ring, uploaded on
 // `stream`.  The caller records t->free after the kernels that read the table.
-// fused: the table feeds a FIR kernel's generator source, which for cosine expects the
-// quarter-cycle advance (gen.cpp:184: phi + 0.25f, one fp32 addition per block) in the table.
 // second: a second table follows at [cap, cap + blocks]: the same phases advanced by
 // `second_offset` (one fp32 addition per block: the quadrature path's phi + (cps*hilb_delay)).
-static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen::Table** out, bool fused = false,
+static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen::Table** out,
                           bool second = false, float second_offset = 0.0f) {
     sdr_gen::Table& t = g->table[g->next_table];
     g->next_table = (g->next_table + 1) % sdr_gen::kRing;
@@ -748,9 +746,8 @@ static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen
     float phi = g->phi;
     const float incr = g->phi_incr;
     float* h = t.h;
-    const float quarter = fused && g->waveform == SDR_WAVE_COSINE ? 0.25f : 0.0f;
     for (size_t b = 0; b < blocks; ++b) {
-        h[b] = phi + quarter;
+        h[b] = phi;
         const float s = phi + incr;
         phi = s >= 1.0f ? s - 1.0f : s;
         if (__builtin_expect(phi >= 1.0f, 0)) phi -= 1.0f; // only if a fract() above rounded up to 1.0
@@ -844,7 +841,7 @@ static int gen_quadrature_impl(sdr_gen* g, size_t blocks, float* d_out, hipStrea
     g->prerolled = true;
     sdr_gen::Table* t = nullptr;
     const float adv = g->cps * (float)hd; // (cycles_per_sample*hilb_delay), gen.cpp:236
-    int rc = gen_next_table(g, blocks, stream, &t, false, true, adv);
+    int rc = gen_next_table(g, blocks, stream, &t, true, adv);
     if (rc != SDR_OK) return rc;
     a.blocks = (long long)blocks;
     a.block_size = (long long)g->block_size;
@@ -893,7 +890,8 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     DeviceGuard guard(f->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     sdr_gen::Table* t = nullptr;
-    rc = gen_next_table(g, blocks, stream, &t, true);
+    const float incr = g->phi_incr; // of this call's blocks
+    rc = gen_next_table(g, blocks, stream, &t);
     if (rc != SDR_OK) return rc;
     FftArgs fa = {};
     fa.in = nullptr;
@@ -908,6 +906,7 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.hist_len = f->hist_len;
     fa.parts = f->fft_parts;
     fa.gen.phi = t->d;
+    fa.gen.phi_incr = incr;
     fa.gen.block_size = (long long)g->block_size;
     fa.gen.inv_block = 1.0 / (double)g->block_size;
     fa.gen.amp = g->amp;
