@@ -217,6 +217,38 @@ def test_generator_fused_into_the_fir_kernel(wf, amp, phase, rate, ntaps2, calls
     assert fused.shape == ref.shape and rel_err(fused, ref) <= TOL
 
 
+@pytest.mark.parametrize("B,nblocks", [(256, 300), (257, 200), (511, 150), (4096, 30), (5000, 20), (65536, 3), (1 << 20, 2)])
+@pytest.mark.parametrize("wf,cps", [("cosine", -0.2137), ("sine", 0.0931), ("triangle", 0.013)])
+def test_fused_generator_block_sizes(B, nblocks, wf, cps):
+    """The fused generator's walk over a tile: generator blocks shorter than a row step of 256 samples
+    would wrap more than once per step (256 is the smallest the fusion takes), blocks of a few rows wrap
+    every few rows and inside waves, blocks longer than a tile never wrap within one.  Two calls, so the
+    phase table of the second starts where the first one's recurrence ended.  Against the oracle's
+    generator (per-block fp32 phase recurrence, gen.cpp:185-227) + staged filters."""
+    import torch
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.12), 0)]
+    amp, phase = 0.8, 77.0
+    gen = sdr_amd.Gen(wf, False, amp, float(np.float32(cps)), phase, B)
+    chain = sdr_amd.Chain(stages, False)
+    calls = [nblocks - nblocks // 3, nblocks // 3] if nblocks >= 3 else [nblocks]
+    total = sum(calls)
+    out = torch.full((total * B,), 777.0, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    done = 0
+    for nb in calls:
+        done += chain.generate_device(gen, nb, out.data_ptr() + 4 * done, stream=stream)
+    torch.cuda.synchronize()
+    assert done == total * B - 63
+    assert bool((out[done:] == 777.0).all())
+    phi0 = np.float32(phase) / np.float32(360.0)
+    x, _ = O.gen_real(total, B, amp, float(np.float32(cps)), float(phi0 - np.floor(phi0)), sdr_amd.WAVEFORMS[wf])
+    ref = staged_oracle(stages, x)
+    got = out[:done].cpu().numpy()
+    rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    err = float(np.max(np.abs(got.astype(np.float64) - ref)))
+    assert err <= TOL * max(rms, amp / np.sqrt(2.0) * 0.05), (B, wf, err / rms)
+
+
 def test_generator_fusion_rejects_what_it_cannot_do():
     B = 2044
     gen_c = sdr_amd.Gen("sine", True, 1.0, 0.1, 0.0, 1022)
