@@ -71,6 +71,25 @@
 #define SDR_CACHE_TBL 0
 #endif
 
+// An exchange's 16 LDS reads are issued as one batch and waited for one by one (1), or left to the compiler's
+// scheduler (0), which strings them out -- read, wait for it, two or three instructions, next read -- and
+// exposes the LDS latency some forty times per tile.  Same box: C5 0.8825 -> 0.8738 ms, C3 0.3917 -> 0.3886,
+// C2 and the 64-channel chain unchanged (profiles/r02_fft_variants.txt).
+#ifndef SDR_READ_BATCH
+#define SDR_READ_BATCH 1
+#endif
+#if SDR_READ_BATCH
+#define SDR_READ_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SDR_READ_FENCE() ((void)0)
+#endif
+// Fused-generator kernels: how many of a stage's fifteen W_256 twiddles (LDS table) are requested in the batch
+// of the stage's data; the rest follow in a second batch behind the butterflies.  1 = each at its use (what the
+// other kernels do: they have no registers to spare, batching costs C2 2.8 %).  C5: 1 0.874, 4 0.863, 8 0.855,
+// 16 0.860 ms on one box.
+#ifndef SDR_TW_BATCH
+#define SDR_TW_BATCH 8
+#endif
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
 // memory pattern.  The release library compiles the switch out.
 #ifdef SDR_AMD_DIAG
@@ -185,8 +204,9 @@ __device__ __forceinline__ void dft16(f2 (&v)[16]) {
 //   TA[k] = W_4096^(tid k), TB[k] = W_256^((tid&15) k), H[k2] = spectrum/N of bin
 //   (tid>>4) + 16 (tid&15) + 256 k2.
 // TBL: the W_256 twiddles are read from a 256-entry LDS table instead of 30 VGPRs.
-template <bool TBL>
+template <bool TBL, int TWB = 1>
 struct LaneConstsT {
+    static constexpr int tw_batch = TBL ? TWB : 1; // see SDR_TW_BATCH
     f2 TA[16], TB[TBL ? 1 : 16], H[16];
     const f2* tb_lds;
     __device__ __forceinline__ f2 tb(int k) const {
@@ -194,6 +214,12 @@ struct LaneConstsT {
         else return TB[k];
     }
     __device__ __forceinline__ f2 ta(int k) const { return TA[k]; }
+    // W_256 twiddles LO..HI-1 of a stage, requested as one batch (TBL: LDS reads)
+    template <int LO, int HI>
+    __device__ __forceinline__ void tb_some(f2 (&t)[16]) const {
+#pragma unroll
+        for (int k = LO; k < HI; ++k) t[k] = tb(k);
+    }
     // wtab: the per-lane twiddles, laid out by the host (double, rounded to fp32) exactly as the lanes take
     // them: wtab[256 k + tid] = W_4096^(tid k) for k = 0..15, then 256 entries W_256^(n k) at [4096 + 16 k + n].
     // 15 coalesced loads per lane (L2-hot: every workgroup reads the same 34 KB) and one LDS write; no
@@ -250,10 +276,18 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     // ---- B: lane (k0, n0 = l16), over n1 -> k1, twiddle W_256^(n0 k1) --------------
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) v[n1] = row1[16 * n1 + l16];
+    f2 tw[16];
+    constexpr int TWN = Consts::tw_batch; // twiddles requested with the data; the rest behind the butterflies
+    c.template tb_some<1, TWN>(tw);
+    SDR_READ_FENCE();
     after_b_reads();
     dft16<false>(v);
+    if (TWN > 1 && TWN < 16) {
+        c.template tb_some<TWN, 16>(tw);
+        SDR_READ_FENCE();
+    }
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], c.tb(k));
+    for (int k = 1; k < 16; ++k) v[P16(k)] = cmul(v[P16(k)], TWN > 1 ? tw[k] : c.tb(k));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 16; ++k) row1[k * 17 + l16] = v[P16(k)];
@@ -262,6 +296,7 @@ __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, cons
     // ---- C: lane (k0, k1 = l16), over n0 -> k2 ------------------------------------
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) v[n0] = row1[l16 * 17 + n0];
+    SDR_READ_FENCE();
     dft16<false>(v);
 }
 
@@ -284,9 +319,19 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
     // ---- B': lane (k0, n0 = l16): conj twiddle, over k1 -> n1 ----------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = row1[k * 17 + l16];
+    f2 tw[16];
+    constexpr int TWN = Consts::tw_batch;
+    c.template tb_some<1, TWN>(tw);
+    SDR_READ_FENCE();
     after_b_reads();
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.tb(k));
+    for (int k = 1; k < TWN; ++k) w[k] = cmulc(w[k], tw[k]);
+    if (TWN > 1 && TWN < 16) {
+        c.template tb_some<TWN, 16>(tw);
+        SDR_READ_FENCE();
+    }
+#pragma unroll
+    for (int k = TWN; k < 16; ++k) w[k] = cmulc(w[k], TWN > 1 ? tw[k] : c.tb(k));
     dft16<true>(w);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -296,6 +341,7 @@ __device__ __forceinline__ void inverse_tile(f2 (&w)[16], f2* lds, int tid, cons
     // ---- A': lane r: conj twiddle, over k0 -> n2 ----------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) w[k] = lds[k * ROW + tid];
+    SDR_READ_FENCE();
 #pragma unroll
     for (int k = 1; k < 16; ++k) w[k] = cmulc(w[k], c.ta(k));
     dft16<true>(w);
@@ -326,7 +372,7 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // gen -> hilbert -> FIR chain writes 4 bytes per sample and reads none.
 // Workgroup `bid` of `nblk` interior workgroups.
 template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
-__device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneConstsT<TBL>& c, const int bid,
+__device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneConstsT<TBL, GEN ? SDR_TW_BATCH : 1>& c, const int bid,
                                                const int nblk) {
     static_assert(!LONG || HQ == 32, "partitioned mode uses hop 2048");
     static_assert(HQ >= 1 && HQ <= 32 && (HQ & (HQ - 1)) == 0, "halo = 64 * {1,2,4,8,16,32}");
@@ -759,7 +805,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     // once per workgroup -- the product then waits on 16 L2 loads and 16 LDS reads instead of 32 L2 loads
     __shared__ __align__(16) f2 lds[16 * ROW + (TBL ? 256 : 0) + ((CACHE && SDR_CACHE_H1_LDS) ? 4096 : 0)];
     int bid = blockIdx.x;
-    LaneConstsT<TBL> c;
+    LaneConstsT<TBL, GEN ? SDR_TW_BATCH : 1> c;
     constexpr bool ONE_LAUNCH = !LONG || (CACHE && SDR_CACHE_ONE_LAUNCH);
     if (ONE_LAUNCH && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
     // (the uncached partitioned variants keep their short work in a launch of its own, fir_fft4096_short)
