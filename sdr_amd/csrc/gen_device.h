@@ -99,17 +99,9 @@ __device__ __forceinline__ float gen_real_sample(int waveform, float amp, float 
     return gen_real_sample_f(waveform, amp, cps, phi, (float)i);
 }
 
-// Same for sine / cosine only: `base` = phi (+0.25 for cosine), no waveform dispatch.
-__device__ __forceinline__ float gen_sine_sample(float amp, float cps, float base, int i) {
-#pragma clang fp contract(off)
-    const float step = cps * (float)i;
-    const float arg = base + step;
-    return amp * wave_sine(arg);
-}
-
 // Two sine / cosine samples at once (the re and im members of a real pair), in-block
 // indices given as floats (exact small integers), `base` = block phase (+0.25 for
-// cosine).  The same roundings in the same order as gen_sine_sample on each component:
+// cosine).  The same roundings in the same order as gen_real_sample's sine on each component:
 // vector operands let the compiler issue v_pk_mul_f32 / v_pk_add_f32, which round each
 // half exactly like the scalar instructions; the fold y > pi/2 ? pi - y : y is
 // min(y, pi - y) on [0, pi]; and because the polynomial is odd (every operation
