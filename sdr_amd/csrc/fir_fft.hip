@@ -90,6 +90,14 @@
 #ifndef SDR_TW_BATCH
 #define SDR_TW_BATCH 8
 #endif
+// spectrum-cache variant: the first partition's spectrum in registers (1) or read from L2 per tile (0).
+// Memory operations return in order: 16 spectrum loads issued in the middle of a tile queue up behind the
+// shares of the next tile's prefetch issued before them, and the product waited out an HBM latency per tile
+// for data that sat in L2.  221 VGPRs with the spectrum resident (the kernel runs two workgroups per CU,
+// 256 each).  C3 0.389 -> 0.360 ms, real samples 0.380 -> 0.352 (same box; profiles/r02_fft_variants.txt).
+#ifndef SDR_CACHE_H0_REGS
+#define SDR_CACHE_H0_REGS 1
+#endif
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
 // memory pattern.  The release library compiles the switch out.
 #ifdef SDR_AMD_DIAG
@@ -571,7 +579,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     else load(in_ptr(cur), nx);
     // the lane constants are set up with the first tile's loads already in flight (every
     // lane of the workgroup gets here or none does: the returns above are uniform)
-    c.init(tid, a.hperm, !LONG, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
+    c.init(tid, a.hperm, !LONG || (CACHE && SDR_CACHE_H0_REGS), reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
     if constexpr (CACHE && SDR_CACHE_H1_LDS) { // each lane reads back only what it wrote itself: no barrier needed
 #pragma unroll
         for (int k = 0; k < 16; ++k) lds[16 * ROW + (TBL ? 256 : 0) + 256 * k + tid] = spectrum(a.hperm, 1, k, tid);
@@ -642,7 +650,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
                          [&] { share(IC<S2>{}, IC<S3>{}); }, [&] { share(IC<S1>{}, IC<S2>{}); });
             share(IC<S3>{}, IC<S4>{});
 #pragma unroll
-            for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], LONG ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
+            for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16(k)], (LONG && !(CACHE && SDR_CACHE_H0_REGS)) ? spectrum(a.hperm, 0, k, tid) : c.H[k]);
             if (CACHE) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
