@@ -269,3 +269,24 @@ def test_stream_filter_zero_copy_pass_and_drop(tmp_path, stdin_kind, stdout_kind
     else:
         assert sent >= big_pass - (5 << 20) * 2 and spliced == 0
     assert skipped >= big_drop - (5 << 20) * 2
+
+
+def test_phase_chain_closed_form_is_the_fp32_recurrence():
+    """sdr_capi.hip gen_next_table / sdr_gen_advance: when the block phase and its increment are whole
+    multiples of 2^-23 below 1, the serial fp32 recurrence phi' = fract(phi + incr) (gen.cpp:185-227) never
+    rounds and equals ((P + k I) mod 2^23) / 2^23 bit for bit -- the form the host then uses."""
+    rng = np.random.default_rng(23)
+    f = np.float32
+    cases = [(0, 0), (0, 1), (1, (1 << 23) - 1), ((1 << 23) - 1, (1 << 23) - 1), (12345, 1 << 22), (0, 3355456)]
+    cases += [(int(rng.integers(0, 1 << 23)), int(rng.integers(0, 1 << 23))) for _ in range(60)]
+    n = 3000
+    for P, I in cases:
+        phi, incr = f(P) / f(1 << 23), f(I) / f(1 << 23)
+        serial = np.empty(n, np.float32)
+        p = phi
+        for b in range(n):
+            serial[b] = p
+            s = f(p + incr)
+            p = f(s - f(1)) if s >= 1 else s
+        closed = ((P + np.arange(n, dtype=np.uint64) * I) & 0x7FFFFF).astype(np.float32) * f(1.0 / (1 << 23))
+        assert np.array_equal(serial.view(np.uint32), closed.view(np.uint32)), (P, I)
