@@ -1,0 +1,24 @@
+"""scripts/exp/long_taps.py -- on the GPU box: the partitioned overlap-save variants beyond 4096 taps
+(parts + 1 transforms per tile, spectra and earlier windows read from L2 mid-tile), ms per launch."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import sdr_amd as S
+n = 1 << 26
+x = (torch.rand((n, 2), device="cuda") * 2 - 1).float()
+y = torch.empty_like(x)
+stream = torch.cuda.current_stream().cuda_stream
+for ntaps in (4095, 6143, 8191, 16383, 32767):
+    taps = S.fir_bandpass(ntaps, 0.05, 0.2)
+    f = S.FirState(taps, True, device=0) if hasattr(S, "FirState") else None
+    for _ in range(5):
+        f.process_device(x.data_ptr(), n, y.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = 20
+    e0.record()
+    for _ in range(K):
+        f.process_device(x.data_ptr(), n, y.data_ptr(), stream=stream)
+    e1.record()
+    torch.cuda.synchronize()
+    print("%6d taps (%2d partitions): %.3f ms per 2^26 complex samples" % (ntaps, (ntaps + 2047) // 2048, e0.elapsed_time(e1) / K), flush=True)
