@@ -249,6 +249,41 @@ def test_fused_generator_block_sizes(B, nblocks, wf, cps):
     assert err <= TOL * max(rms, amp / np.sqrt(2.0) * 0.05), (B, wf, err / rms)
 
 
+@pytest.mark.parametrize("B", [256, 2044])
+def test_fused_generator_retuned_and_advanced_between_calls(B):
+    """Frequency changes and skipped packets between calls of the fused chain: the host's phase table switches
+    between its two forms (closed form when phase and increment are multiples of 2^-23, the serial fp32
+    recurrence otherwise -- a frequency of 1e-5 cycles per sample gives an increment with finer bits), and
+    every segment must continue the phase the previous one left (gen.cpp:185-227, :124 for the increment)."""
+    import torch
+    stages = [(sdr_amd.hilbert(31), 15), (sdr_amd.fir_lowpass(63, 0.2), 0)]
+    amp, phase = 1.25, 30.0
+    plan = [(0.0931, 40, 0), (1e-5, 25, 3), (-0.2137, 33, 0), (3.3e-4, 20, 7), (0.125, 30, 1)]  # cps, blocks, packets skipped first
+    gen = sdr_amd.Gen("sine", False, amp, float(np.float32(plan[0][0])), phase, B)
+    chain = sdr_amd.Chain(stages, False)
+    total = sum(nb for _, nb, _ in plan)
+    out = torch.full((total * B,), 777.0, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    phi = np.float32(phase) / np.float32(360.0)
+    phi = float(phi - np.floor(phi))
+    xs, done = [], 0
+    for cps, nb, skip in plan:
+        cps = float(np.float32(cps))
+        gen.set_frequency(cps)
+        if skip:
+            gen.advance(skip)
+            _, phi = O.gen_real(skip, B, amp, cps, phi, sdr_amd.WAVEFORMS["sine"])
+        done += chain.generate_device(gen, nb, out.data_ptr() + 4 * done, stream=stream)
+        x, phi = O.gen_real(nb, B, amp, cps, phi, sdr_amd.WAVEFORMS["sine"])
+        xs.append(x)
+    torch.cuda.synchronize()
+    ref = staged_oracle(stages, np.concatenate(xs))
+    assert done == ref.shape[0] and bool((out[done:] == 777.0).all())
+    got = out[:done].cpu().numpy()
+    rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= TOL * rms
+
+
 def test_generator_fusion_rejects_what_it_cannot_do():
     B = 2044
     gen_c = sdr_amd.Gen("sine", True, 1.0, 0.1, 0.0, 1022)
