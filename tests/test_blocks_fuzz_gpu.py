@@ -65,5 +65,11 @@ def test_random_packet_streams(seed):
     if fb and sum(len(v) for v in fb) > 16:
         a, b = np.concatenate(fa).astype(np.float64), np.concatenate(fb).astype(np.float64)
         rms = np.sqrt(np.mean(b ** 2))
+        # a stream shorter than the transformer's delay is all onset: its outputs lie far below the level the
+        # block settles at (unit gain: the input's RMS), while the overlap-save kernel rounds at the level of
+        # the whole filter -- there the bar is 1e-5 of a twentieth of the settled level (tests/test_fuzz_gpu.py)
+        mine = [np.frombuffer(d, np.float32).astype(np.float64) for q, k, d, _ in parts
+                if q == my_id and k in (O.SIGNAL, O.COMPLEX_SIGNAL) and len(d)]
+        settled = float(np.sqrt(np.mean(np.concatenate(mine) ** 2))) if mine else 0.0
         if rms > 0:
-            assert np.max(np.abs(a - b)) <= TOL * rms, (seed, taps, delay, float(np.max(np.abs(a - b)) / rms))
+            assert np.max(np.abs(a - b)) <= TOL * max(rms, 0.05 * settled), (seed, taps, delay, float(np.max(np.abs(a - b)) / rms))
