@@ -161,6 +161,12 @@ extern "C" int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t
     // every copy and launch below belongs to the chain's device, whatever device is current
     sdr_amd::DeviceGuard guard(c->device);
     if (guard.err != hipSuccess) return hipfail(guard.err, "hipSetDevice");
+    // Past the start of the stream a chain call is one call of the fused filter, whose stream position is
+    // device state: safe to record into a HIP graph and replay.  Inside the start-of-stream region the work
+    // depends on the host-side position (swallowed outputs, staged warm-up): refused rather than recorded.
+    if (c->pos < std::max(c->prefix, c->total_skip) && sdr_amd::stream_is_capturing(stream))
+        return fail(SDR_ERR_INVALID, "sdr_chain_process_device: the start-of-stream region (group-delay skip, staged warm-up) "
+                                     "cannot be recorded into a HIP graph; capture a later call");
     c->dirty = true;
     const size_t w = c->w, fw = w * sizeof(float);
     const float* in = (const float*)d_in;

@@ -102,8 +102,10 @@
 // memory pattern.  The release library compiles the switch out.
 #ifdef SDR_AMD_DIAG
 #define SDR_ABLATE(a) ((a).ablate)
+#define SDR_CONTIG(a) ((a).contig)
 #else
 #define SDR_ABLATE(a) 0
+#define SDR_CONTIG(a) 0
 #endif
 namespace sdr_amd {
 
@@ -399,7 +401,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
     // 64-bit divisions; tt counts tiles of the channel from a.t_lo
     // tile -> workgroup: contiguous runs (always with the spectrum cache; a.contig for
     // the others) or grid-strided
-    const bool runs = CACHE || a.contig;
+    const bool runs = CACHE || SDR_CONTIG(a);
     struct Pos { long long ch, tt; };
     auto advance = [&](Pos p) {
         p.tt += runs ? 1 : nblk;
@@ -721,7 +723,8 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
 // short call.  Bounds-checked, runtime halo / parts, no pipelining.  Workgroup `bid` of
 // `nblk` edge workgroups.
 template <bool REAL, bool GEN, class Consts>
-__device__ __forceinline__ void edge_tiles(const FftArgs& a, f2* lds, const Consts& c, const int bid, const int nblk) {
+__device__ __forceinline__ void edge_tiles(const FftArgs& a, const float* hist_base, f2* lds, const Consts& c, const int bid,
+                                           const int nblk) {
     static_assert(!GEN || REAL, "the generator source produces real samples");
     const int tid = threadIdx.x;
     constexpr int W = REAL ? 1 : 2;
@@ -738,7 +741,7 @@ __device__ __forceinline__ void edge_tiles(const FftArgs& a, f2* lds, const Cons
         long long tt = e - ch * edge_per_ch;
         if (skipped && tt >= a.t_lo) tt += skipped;
         const float* in = a.in + ch * a.in_stride * W;
-        const float* hist = a.hist + ch * (long long)a.hist_len * W;
+        const float* hist = hist_base + ch * (long long)a.hist_len * W;
         float* out = a.out + ch * a.out_stride * W;
         const long long o0 = tt * per_tile; // first output of the tile
         auto sample = [&](long long m, int k) -> float { // virtual stream: history | input | 0
@@ -784,8 +787,10 @@ __device__ __forceinline__ void edge_tiles(const FftArgs& a, f2* lds, const Cons
 // ---- history carry: after the call the other history buffer holds the last hist_len
 // samples of the virtual stream (old history | this call's input or synthesised samples).
 // Reads only what the call's other workgroups read; writes a buffer none of them touches.
+// Which buffer is which is device state (FirDevState::cur), flipped by call_done below.
 template <bool GEN>
-__device__ __forceinline__ void carry_history(const FftArgs& a, const int w, const int bid, const int nblk) {
+__device__ __forceinline__ void carry_history(const FftArgs& a, const float* old_hist, float* new_hist, const int w, const int bid,
+                                              const int nblk) {
     const long long total = (long long)a.hist_len * w * a.channels;
     for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
         const long long ch = i / (a.hist_len * w);
@@ -793,10 +798,26 @@ __device__ __forceinline__ void carry_history(const FftArgs& a, const int w, con
         const int s = r / w, k = r - s * w;
         const long long m = a.n - a.hist_len + s;
         float v;
-        if (m < 0) v = a.hist[(ch * a.hist_len + (a.hist_len + m)) * w + k];
+        if (m < 0) v = old_hist[(ch * a.hist_len + (a.hist_len + m)) * w + k];
         else if constexpr (GEN) v = gen_src_at(a.gen, m);
         else v = a.in[(ch * a.in_stride + m) * w + k];
-        a.new_hist[i] = v;
+        new_hist[i] = v;
+    }
+}
+
+// ---- end of a call (every workgroup of the call's last launch, at its very end).  The workgroup that
+// finishes last leaves the handle's device state ready for the next launch on the stream: ticket
+// counters back to zero, history buffers swapped.  Nothing of this is host state, so a captured
+// graph of one call replays as the stream's next call (tests/test_graph_capture_gpu.py).
+__device__ __forceinline__ void call_done(const FftArgs& a, const unsigned cur) {
+    __syncthreads(); // every wave of the workgroup is past its reads of the state, the history and its tickets
+    if (last_workgroup_done(a.state, gridDim.x)) {
+        if (a.tickets) {
+#pragma unroll
+            for (int t = 0; t < FFT_TICKETS; ++t) a.tickets[FFT_TICKET_STRIDE * t] = 0;
+        }
+        a.state->done = 0;
+        a.state->cur = cur ^ 1u;
     }
 }
 
@@ -815,40 +836,41 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     int bid = blockIdx.x;
     LaneConstsT<TBL, GEN ? SDR_TW_BATCH : 1> c;
     constexpr bool ONE_LAUNCH = !LONG || (CACHE && SDR_CACHE_ONE_LAUNCH);
-    if (ONE_LAUNCH && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
-    // (the uncached partitioned variants keep their short work in a launch of its own, fir_fft4096_short)
+    // (the uncached partitioned variants keep their short work in a launch of its own, fir_fft4096_short,
+    // which also ends the call; their interior workgroups touch neither history nor state)
     if constexpr (ONE_LAUNCH) {
+        const unsigned cur = a.state->cur & 1u;
         if (bid < a.grid_carry) {
-            carry_history<GEN>(a, REAL ? 1 : 2, bid, a.grid_carry);
-            return;
-        }
-        bid -= a.grid_carry;
-        if (bid < a.grid_edge) {
+            carry_history<GEN>(a, a.hist[cur], a.hist[cur ^ 1u], REAL ? 1 : 2, bid, a.grid_carry);
+        } else if (bid < a.grid_carry + a.grid_edge) {
             c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
-            edge_tiles<REAL, GEN>(a, lds, c, bid, a.grid_edge);
-            return;
+            edge_tiles<REAL, GEN>(a, a.hist[cur], lds, c, bid - a.grid_carry, a.grid_edge);
+        } else {
+            interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid - a.grid_carry - a.grid_edge,
+                                                            (int)gridDim.x - a.grid_carry - a.grid_edge);
         }
-        bid -= a.grid_edge;
+        call_done(a, cur);
+    } else {
+        interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid, (int)gridDim.x);
     }
-    interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
-                                                    ONE_LAUNCH ? (int)gridDim.x - a.grid_carry - a.grid_edge : (int)gridDim.x);
 }
 
 // carry + edge workgroups alone (partitioned filters; calls without interior tiles)
 template <bool REAL, bool GEN>
 __global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * ROW + 256];
-    int bid = blockIdx.x;
-    // partitioned filters: this launch follows the main one on the stream and is never empty
-    if (a.parts > 1 && bid == 0 && a.tickets_next && threadIdx.x < FFT_TICKETS) a.tickets_next[FFT_TICKET_STRIDE * threadIdx.x] = 0;
+    const int bid = blockIdx.x;
+    // partitioned filters: this launch follows the main one on the stream, is never empty (the history is
+    // always carried) and ends the call: its last workgroup zeroes the main launch's tickets and swaps the histories
+    const unsigned cur = a.state->cur & 1u;
     if (bid < a.grid_carry) {
-        carry_history<GEN>(a, REAL ? 1 : 2, bid, a.grid_carry);
-        return;
+        carry_history<GEN>(a, a.hist[cur], a.hist[cur ^ 1u], REAL ? 1 : 2, bid, a.grid_carry);
+    } else {
+        LaneConstsT<true> c;
+        c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, lds + 16 * ROW);
+        edge_tiles<REAL, GEN>(a, a.hist[cur], lds, c, bid - a.grid_carry, a.grid_edge);
     }
-    bid -= a.grid_carry;
-    LaneConstsT<true> c;
-    c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, lds + 16 * ROW);
-    edge_tiles<REAL, GEN>(a, lds, c, bid, a.grid_edge);
+    call_done(a, cur);
 }
 
 template <bool REAL, bool GEN>
@@ -916,10 +938,9 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     // ordered tickets: every variant but the spectrum cache (its workgroups walk runs) and the diagnostic
     // contiguous mode; 32-bit flat tile indices; every workgroup must be resident from the start (a
     // workgroup that starts late would take its two static tiles at the very end)
-    const bool ticketed = a.tickets && a.parts != 2 && !a.contig && inner > 0 &&
-                          inner * a.channels + 4LL * grid_blocks < (1LL << 31);
-    if (!ticketed) a.tickets = nullptr;
-    else if (a.resident > 0 && grid_blocks > a.resident) grid_blocks = a.resident;
+    bool ticketed = a.tickets && a.parts != 2 && !SDR_CONTIG(a) && inner > 0 &&
+                    inner * a.channels + 4LL * grid_blocks < (1LL << 31);
+    if (ticketed && a.resident > 0 && grid_blocks > a.resident) grid_blocks = a.resident;
     if (inner > 0) {
         const long long total = inner * a.channels;
         // a short call: at least two tiles per workgroup (its set-up costs about one), down to
@@ -930,10 +951,14 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
         const long long rounds = (total + grid_blocks - 1) / grid_blocks;
         grid_int = (total + rounds - 1) / rounds;
     }
+    // a workgroup draws from counter bid % FFT_TICKETS: with fewer workgroups than counters some counters --
+    // and the tiles they stand for -- would have no workgroup.  Such grids (tests, tiny calls) walk grid-strided.
+    if (grid_int < FFT_TICKETS) ticketed = false;
+    if (!ticketed) a.tickets = nullptr;
     const long long edge = (tiles_per_ch - inner) * a.channels;
     a.grid_edge = (int)(edge < grid_blocks ? edge : grid_blocks);
     const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
-    a.grid_carry = a.new_hist ? (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64) : 0;
+    a.grid_carry = (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64); // >= 1: every call carries
     if (a.gen.enabled) return launch_tiles<true, true>(a, grid_int, stream);
     return real ? launch_tiles<true, false>(a, grid_int, stream) : launch_tiles<false, false>(a, grid_int, stream);
 }

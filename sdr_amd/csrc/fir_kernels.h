@@ -9,10 +9,27 @@
 
 namespace sdr_amd {
 
+// Where a handle's stream stands, in DEVICE memory: every launch reads it, the last workgroup of a
+// call's last launch to finish moves it on.  Nothing about the stream's position is host state, so
+// a captured graph of one call replays as the next call of the stream, and replays mix freely with
+// direct calls (the reference's kfr::fir_state lives across calls, libs/kfr/dsp/fir.hpp:57-68).
+struct FirDevState {
+    unsigned cur;  // which of the two history buffers holds the last hist_len samples of the stream
+    unsigned done; // workgroups of the running launch that have finished (back to 0 when it ends)
+};
+
+// The workgroup that finishes last gets true (thread 0 only; call from every workgroup of the launch,
+// `nblk` of them, behind a barrier that every wave reaches after its last read of *st).
+__device__ __forceinline__ bool last_workgroup_done(FirDevState* st, unsigned nblk) {
+    if (threadIdx.x != 0) return false;
+    return __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == nblk;
+}
+
 struct FirArgs {
     const float* in;      // channel 0, sample 0
     float* out;           // channel 0, output 0
-    const float* hist;    // [channels][hist_len] samples preceding `in`
+    const float* hist[2]; // [channels][hist_len] samples preceding `in`: the buffer state->cur names
+    const FirDevState* state; // NULL: hist[0]
     const float* taps;    // compacted (every STRIDE-th) taps, zero-padded to nchunks*R/STRIDE
     long long n;          // samples per channel
     long long in_stride;  // samples between channels
@@ -36,7 +53,9 @@ struct KernelInfo {
 struct FftArgs {
     const float* in;
     float* out;
-    const float* hist;    // [channels][hist_len]
+    float* hist[2];       // [channels][hist_len] each: state->cur names the one that precedes `in`; the launch
+                          // fills the other and flips state->cur when its last workgroup is done
+    FirDevState* state;
     const float* hperm;   // parts x 4096 complex: H_p[k]/N stored at [p*4096 + k2*256 + 16*k0 + k1], k = k0 + 16 k1 + 256 k2
     const float* wtab;    // 4096 + 256 complex: W_4096^(tid k) at [256 k + tid], W_256^(n k) at [4096 + 16 k + n]
     long long n;
@@ -45,19 +64,18 @@ struct FftArgs {
     long long channels;
     int halo;             // old samples per tile: >= ntaps-1; 64 * {1,2,4,8,16,32}
     int hist_len;         // >= halo
-    int ablate;           // read by -DSDR_AMD_DIAG builds only: 1 = skip the arithmetic (memory pattern only)
     int parts;            // filter partitions of 2048 taps (1 = plain overlap-save)
+#ifdef SDR_AMD_DIAG       // diagnostic builds only (make diag, scripts/exp)
+    int ablate;           // 1 = skip the arithmetic (memory pattern only)
     int contig;           // every workgroup walks a contiguous run of tiles instead of a grid-strided set
-    float* new_hist;      // [channels][hist_len]: receives the history after this call (NULL: not carried)
+#endif
     long long t_lo, t_hi; // set by launch_fir_fft: tiles [t_lo, t_hi) of each channel are interior tiles
     int grid_carry, grid_edge; // set by launch_fir_fft: leading workgroups that carry the history / take edge tiles
     GenSrc gen;           // gen.enabled: samples 0..n-1 are synthesised (real, one channel), `in` is unused
     // Ordered tile hand-out (fir_fft.hip, interior_tiles): FFT_TICKETS counters, FFT_TICKET_STRIDE words
-    // apart, all zero when the launch starts; the launch zeroes `tickets_next`, the set the handle's next
-    // launch will use (launches on one handle are stream-ordered, like the history swap).  NULL: tiles
-    // are grid-strided.
+    // apart, all zero when the launch starts; the call's last workgroup to finish zeroes them again
+    // (launches on one handle are stream-ordered).  NULL: tiles are grid-strided.
     unsigned* tickets;
-    unsigned* tickets_next;
     int resident;         // workgroups of the single-partition kernels resident on the device at once (0: unknown)
 };
 #ifndef SDR_FFT_TICKETS
@@ -65,7 +83,7 @@ struct FftArgs {
 #endif
 constexpr int FFT_TICKETS = SDR_FFT_TICKETS;
 constexpr int FFT_TICKET_STRIDE = 64;
-constexpr size_t FFT_TICKET_WORDS = 2 * FFT_TICKETS * FFT_TICKET_STRIDE; // both sets
+constexpr size_t FFT_TICKET_WORDS = FFT_TICKETS * FFT_TICKET_STRIDE;
 hipError_t launch_fir_fft(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
 const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);
@@ -87,7 +105,8 @@ void plan_direct_fill(const float* taps, const DirectPlan& p, float* g);
 struct MfmaArgs {
     const float* in;
     float* out;
-    const float* hist;   // [channels][hist_len]
+    const float* hist[2]; // [channels][hist_len]: the buffer state->cur names
+    const FirDevState* state;
     const float* atab;   // smax x 64: the taps operand of every step, per lane
     long long n;         // samples per channel
     long long in_stride;
@@ -105,7 +124,8 @@ const KernelInfo* find_kernel(int R, int stride, bool real);
 size_t kernel_lds_bytes(const KernelInfo& k, int nchunks);
 hipError_t prepare_kernel(const KernelInfo& k, int nchunks);
 hipError_t launch_fir(const KernelInfo& k, const FirArgs& a, size_t channels, hipStream_t stream);
-hipError_t launch_carry_history(const float* in, long long in_stride, long long n, const float* old_hist,
-                                float* new_hist, int hist_len, int w, size_t channels, hipStream_t stream);
+// the last hist_len samples of (history state->cur | in) into the other history buffer, then state->cur flips
+hipError_t launch_carry_history(const float* in, long long in_stride, long long n, float* const hist[2],
+                                FirDevState* state, int hist_len, int w, size_t channels, hipStream_t stream);
 
 } // namespace sdr_amd

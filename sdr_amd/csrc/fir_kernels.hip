@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void fir_direct(FirArgs a) {
 
     Stream<REAL ? 1 : 2> src;
     src.in = a.in + ch * a.in_stride * (REAL ? 1 : 2);
-    src.hist = a.hist + ch * (long long)a.hist_len * (REAL ? 1 : 2);
+    src.hist = a.hist[a.state ? a.state->cur & 1u : 0u] + ch * (long long)a.hist_len * (REAL ? 1 : 2);
     src.n = a.n;
     src.hist_len = a.hist_len;
     src.vec_ok = a.vec_in;
@@ -223,13 +223,17 @@ __global__ __launch_bounds__(256) void fir_direct(FirArgs a) {
     }
 }
 
-// new_hist[i] = virtual x[n - hist_len + i]; reads the OLD history for the part
-// of the window that precedes this call's input (n < hist_len).
+// new_hist[i] = virtual x[n - hist_len + i]; reads the OLD history (the buffer state->cur names) for
+// the part of the window that precedes this call's input (n < hist_len), writes the other buffer.
+// This is the last launch of a direct-form / matrix-core call: its last workgroup to finish flips
+// state->cur, so the next launch on the stream -- a new call or a replay of this one -- reads on.
 __global__ void fir_carry_history(const float* __restrict__ in, long long in_stride, long long n,
-                                  const float* __restrict__ old_hist, float* __restrict__ new_hist,
-                                  int hist_len, int w) {
+                                  float* hist0, float* hist1, FirDevState* state, int hist_len, int w) {
     const long long ch = blockIdx.y;
     const int total = hist_len * w;
+    const unsigned cur = state->cur & 1u;
+    const float* __restrict__ old_hist = cur ? hist1 : hist0;
+    float* __restrict__ new_hist = cur ? hist0 : hist1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int s = i / w, k = i - s * w;
         const long long m = n - hist_len + s;
@@ -237,6 +241,11 @@ __global__ void fir_carry_history(const float* __restrict__ in, long long in_str
         if (m >= 0) v = in[(ch * in_stride + m) * w + k];
         else v = old_hist[(ch * hist_len + (hist_len + m)) * w + k];
         new_hist[ch * (long long)total + i] = v;
+    }
+    __syncthreads(); // every wave of the workgroup has read state->cur
+    if (last_workgroup_done(state, gridDim.x * gridDim.y)) {
+        state->done = 0;
+        state->cur = cur ^ 1u;
     }
 }
 
@@ -292,13 +301,13 @@ hipError_t prepare_kernel(const KernelInfo& k, int nchunks) {
     return hipSuccess;
 }
 
-hipError_t launch_carry_history(const float* in, long long in_stride, long long n, const float* old_hist,
-                                float* new_hist, int hist_len, int w, size_t channels, hipStream_t stream) {
+hipError_t launch_carry_history(const float* in, long long in_stride, long long n, float* const hist[2],
+                                FirDevState* state, int hist_len, int w, size_t channels, hipStream_t stream) {
     if (channels == 0) return hipSuccess;
     const int total = hist_len * w;
     const int blocks = (total + 255) / 256;
     hipLaunchKernelGGL(fir_carry_history, dim3(blocks > 0 ? blocks : 1, (unsigned)channels, 1), dim3(256), 0, stream,
-                       in, in_stride, n, old_hist, new_hist, hist_len, w);
+                       in, in_stride, n, hist[0], hist[1], state, hist_len, w);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
 
     MStream<W> src;
     src.in = a.in + ch * a.in_stride * W;
-    src.hist = a.hist + ch * (long long)a.hist_len * W;
+    src.hist = a.hist[a.state ? a.state->cur & 1u : 0u] + ch * (long long)a.hist_len * W;
     src.n = a.n;
     src.hist_len = a.hist_len;
     src.vec_ok = a.vec_in;
@@ -188,7 +188,11 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
             }
         }
     }
+    // the accumulators were written by one lane and are read back by others of the same wave: the
+    // fences order that hand-off by construction (wave_barrier alone only pins the schedule)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float* out = a.out + ch * a.out_stride * W;
     const long long nfl = a.n * W; // floats per channel
 #pragma unroll

@@ -25,6 +25,9 @@ struct DeviceGuard {
     }
 };
 
+// True while `s` is recording into a HIP graph (sdr_capi.hip).
+bool stream_is_capturing(hipStream_t s);
+
 // Like sdr_fir_process_device with the generator's next `blocks` packets as the input,
 // synthesised inside the FIR kernel (nothing is written but the blocks*B outputs).
 // Needs the overlap-save path, real samples, one channel, 256 <= B <= 2^23.

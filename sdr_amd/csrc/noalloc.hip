@@ -116,7 +116,8 @@ extern "C" int sdr_fir_apply_device_noalloc(const float* taps, size_t ntaps, int
     FirArgs a;
     a.in = (const float*)d_in;
     a.out = (float*)d_out;
-    a.hist = ptr + kTapsFloats;
+    a.hist[0] = a.hist[1] = ptr + kTapsFloats;
+    a.state = nullptr; // stateless: always the zero history
     a.taps = ptr;
     a.n = (long long)n;
     a.in_stride = a.out_stride = (long long)n;

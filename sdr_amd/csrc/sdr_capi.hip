@@ -33,6 +33,18 @@ static int hip_fail(hipError_t e, const char* what) {
     return fail(code, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// A stream under HIP graph capture records work instead of running it.  The FIR entry points are safe to
+// capture (their stream position is device state); calls whose work depends on host-side stream position
+// ask this and refuse with a message instead of recording something that replays wrongly.
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 #define SDR_HIP(expr)                                              \
     do {                                                           \
         hipError_t e_ = (expr);                                    \
@@ -61,7 +73,9 @@ struct sdr_fir {
     int fft_halo = 0;
     int fft_parts = 1;
     int fft_grid = 0;
+#ifdef SDR_AMD_DIAG
     int fft_ablate = 0, fft_contig = 0; // diagnostics (SDR_AMD_FFT_ABLATE / SDR_AMD_FFT_CONTIG), read at create
+#endif
     float* d_hperm = nullptr;
     const float* d_wtab = nullptr; // per-lane twiddle tables, stored behind the spectra in d_hperm
     // Real samples, every other tap zero (the Hilbert design: non-zero taps on the even indices): y[n] depends on
@@ -71,11 +85,13 @@ struct sdr_fir {
     bool fft_pair = false;
     int pair_halo = 0, pair_parts = 1, pair_grid = 0, pair_resident = 0;
     float* d_hperm_pair = nullptr; // spectra of the kept taps
-    unsigned* d_tickets = nullptr; // two sets of tile-ticket counters behind the twiddle table (FftArgs::tickets)
-    int tick = 0;                  // the set the next overlap-save launch uses
+    unsigned* d_tickets = nullptr; // tile-ticket counters behind the twiddle table (FftArgs::tickets): zero between calls
     int fft_resident = 0;
+    // The stream's history: the last hist_len samples, in one of two buffers; WHICH one is device state
+    // (d_state->cur), read and flipped by the kernels themselves.  The host keeps no position of the
+    // stream, so graph replays of a captured call and direct calls continue one another.
     float* d_hist[2] = {nullptr, nullptr};
-    int cur = 0;
+    FirDevState* d_state = nullptr;
     // Host-buffer entry points: one stream per staging slot, so that the device-to-host copy of
     // batch k (slot s) overlaps the host-to-device copy of batch k+1 (slot s^1) -- PCIe is full
     // duplex.  The filter kernels still run in submission order: each waits for the event recorded
@@ -259,6 +275,8 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if ((e = hipMalloc(&f->d_taps, g.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(taps)");
     if ((e = hipMalloc(&f->d_hist[0], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
     if ((e = hipMalloc(&f->d_hist[1], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
+    if ((e = hipMalloc(&f->d_state, 256)) != hipSuccess) return bail(e, "hipMalloc(state)");
+    if ((e = hipMemset(f->d_state, 0, 256)) != hipSuccess) return bail(e, "hipMemset(state)");
     if ((e = hipMemcpy(f->d_taps, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(taps)");
     if (use_mfma) {
@@ -338,8 +356,10 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         f->pair_resident = cus * (f->pair_parts > 1 ? 2 : 3);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
         f->fft_grid = std::max(1, env_int("SDR_AMD_FFT_GRID", grid > 0 ? grid : f->fft_grid));
+#ifdef SDR_AMD_DIAG
         f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
         f->fft_contig = env_int("SDR_AMD_FFT_CONTIG", 0);
+#endif
     }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
@@ -388,19 +408,27 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (f->d_hperm_pair) (void)hipFree(f->d_hperm_pair);
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
+    if (f->d_state) (void)hipFree(f->d_state);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     if (f->stream1) (void)hipStreamDestroy(f->stream1);
     if (f->filtered) (void)hipEventDestroy(f->filtered);
     delete f;
 }
 
-// ticket counters of one overlap-save launch (FftArgs::tickets): the launch uses one set and zeroes the other
-static void take_tickets(sdr_fir* f, FftArgs& fa) {
-    fa.tickets = f->d_tickets + (size_t)f->tick * FFT_TICKETS * FFT_TICKET_STRIDE;
-    fa.tickets_next = f->d_tickets + (size_t)(f->tick ^ 1) * FFT_TICKETS * FFT_TICKET_STRIDE;
+// what every overlap-save launch of a handle shares: history buffers, device state, ticket counters (zero
+// between calls: the call's last workgroup to finish zeroes them), twiddles
+static void fft_common_args(sdr_fir* f, FftArgs& fa) {
+    fa.hist[0] = f->d_hist[0];
+    fa.hist[1] = f->d_hist[1];
+    fa.state = f->d_state;
+    fa.wtab = f->d_wtab;
+    fa.tickets = f->d_tickets;
     fa.resident = env_int("SDR_AMD_FFT_RESIDENT", f->fft_resident);
-    f->tick ^= 1;
-    if (!env_int("SDR_AMD_FFT_TICKETS", 1)) fa.tickets = fa.tickets_next = nullptr; // diagnostic builds only
+    if (!env_int("SDR_AMD_FFT_TICKETS", 1)) fa.tickets = nullptr; // diagnostic builds only
+#ifdef SDR_AMD_DIAG
+    fa.ablate = f->fft_ablate;
+    fa.contig = f->fft_contig;
+#endif
 }
 
 static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, size_t n, float* d_out,
@@ -422,14 +450,9 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         FftArgs fa = {};
         fa.in = d_in;
         fa.out = d_out;
-        fa.hist = f->d_hist[f->cur];
-        fa.wtab = f->d_wtab;
         fa.channels = (long long)f->channels;
         fa.t_lo = fa.t_hi = 0;
-        fa.ablate = f->fft_ablate;
-        fa.contig = f->fft_contig;
-        fa.new_hist = f->d_hist[f->cur ^ 1];
-        take_tickets(f, fa);
+        fft_common_args(f, fa);
         // real samples as complex pairs (see sdr_fir::fft_pair) when this call's shape allows it; either view
         // leaves the same history behind, so calls of both kinds mix freely
         const bool pair = f->fft_pair && n % 2 == 0 && ((uintptr_t)d_in % 8 == 0) && ((uintptr_t)d_out % 8 == 0) &&
@@ -454,7 +477,6 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
             fa.parts = f->fft_parts;
             SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         }
-        f->cur ^= 1;
         return SDR_OK;
     }
     const bool multi = f->channels > 1;
@@ -464,7 +486,9 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         MfmaArgs m;
         m.in = d_in;
         m.out = d_out;
-        m.hist = f->d_hist[f->cur];
+        m.hist[0] = f->d_hist[0];
+        m.hist[1] = f->d_hist[1];
+        m.state = f->d_state;
         m.atab = f->d_atab;
         m.n = (long long)n;
         m.in_stride = (long long)in_stride;
@@ -473,15 +497,16 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         m.vec_in = vec_in;
         m.vec_out = vec_out;
         SDR_HIP(launch_fir_mfma(m, f->kind == SDR_REAL, f->k->stride, f->mfma_smax, f->channels, stream));
-        SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
-                                     f->hist_len, f->w, f->channels, stream));
-        f->cur ^= 1;
+        SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist, f->d_state, f->hist_len, f->w,
+                                     f->channels, stream));
         return SDR_OK;
     }
     FirArgs a;
     a.in = d_in;
     a.out = d_out;
-    a.hist = f->d_hist[f->cur];
+    a.hist[0] = f->d_hist[0];
+    a.hist[1] = f->d_hist[1];
+    a.state = f->d_state;
     a.taps = f->d_taps;
     a.n = (long long)n;
     a.in_stride = (long long)in_stride;
@@ -492,9 +517,8 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
     a.vec_in = vec_in;
     a.vec_out = vec_out;
     SDR_HIP(launch_fir(*f->k, a, f->channels, stream));
-    SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist[f->cur], f->d_hist[f->cur ^ 1],
-                                 f->hist_len, f->w, f->channels, stream));
-    f->cur ^= 1;
+    SDR_HIP(launch_carry_history(d_in, (long long)in_stride, (long long)n, f->d_hist, f->d_state, f->hist_len, f->w,
+                                 f->channels, stream));
     return SDR_OK;
 }
 
@@ -576,13 +600,18 @@ extern "C" int sdr_fir_reset(sdr_fir_t* f) {
     clear_error();
     if (!f) return fail(SDR_ERR_INVALID, "sdr_fir_reset: NULL handle");
     DeviceGuard guard(f->device);
+    // The handle's own streams are drained; work the caller queued on a stream of their own
+    // (sdr_fir_process_device) is theirs to order before a reset, like before a destroy.  The clears go
+    // through the handle's stream and are waited for, so the next call on any stream sees them.
     SDR_HIP(hipStreamSynchronize(f->stream));
     SDR_HIP(hipStreamSynchronize(f->stream1));
-    SDR_HIP(hipDeviceSynchronize());
     f->have_filtered = false;
     const size_t hist_bytes = f->channels * (size_t)f->hist_len * f->w * sizeof(float);
-    SDR_HIP(hipMemset(f->d_hist[0], 0, hist_bytes));
-    SDR_HIP(hipMemset(f->d_hist[1], 0, hist_bytes));
+    SDR_HIP(hipMemsetAsync(f->d_hist[0], 0, hist_bytes, f->stream));
+    SDR_HIP(hipMemsetAsync(f->d_hist[1], 0, hist_bytes, f->stream));
+    SDR_HIP(hipMemsetAsync(f->d_state, 0, 256, f->stream));
+    if (f->d_tickets) SDR_HIP(hipMemsetAsync(f->d_tickets, 0, FFT_TICKET_WORDS * sizeof(unsigned), f->stream));
+    SDR_HIP(hipStreamSynchronize(f->stream));
     return SDR_OK;
 }
 
@@ -746,6 +775,9 @@ extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
 // `second_offset` (one fp32 addition per block: the quadrature path's phi + (cps*hilb_delay)).
 static int gen_next_table(sdr_gen* g, size_t blocks, hipStream_t stream, sdr_gen::Table** out,
                           bool second = false, float second_offset = 0.0f) {
+    if (stream_is_capturing(stream))
+        return fail(SDR_ERR_INVALID, "generator: this call uploads a per-call phase table computed on the host (the reference's "
+                                     "sequential fp32 phase recurrence, blocks/gen.cpp:185) and cannot be recorded into a HIP graph");
     sdr_gen::Table& t = g->table[g->next_table];
     g->next_table = (g->next_table + 1) % sdr_gen::kRing;
     SDR_HIP(hipEventSynchronize(t.free)); // the call that used this slot 4 calls ago
@@ -924,9 +956,7 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     FftArgs fa = {};
     fa.in = nullptr;
     fa.out = d_out;
-    fa.hist = f->d_hist[f->cur];
     fa.hperm = f->d_hperm;
-    fa.wtab = f->d_wtab;
     fa.n = (long long)(blocks * g->block_size);
     fa.in_stride = fa.out_stride = fa.n;
     fa.channels = 1;
@@ -941,10 +971,8 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.gen.cps = g->cps;
     fa.gen.waveform = g->waveform;
     fa.gen.enabled = 1;
-    fa.new_hist = f->d_hist[f->cur ^ 1];
-    take_tickets(f, fa);
+    fft_common_args(f, fa);
     SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
-    f->cur ^= 1;
     SDR_HIP(hipEventRecord(t->free, stream));
     return SDR_OK;
 }
