@@ -32,6 +32,7 @@
 // fp32 error: ~3e-7 of the tile's RMS (measured against a float64 convolution), inside
 // the 1e-5 bar; unlike the direct form it is relative to the tile, not to each output.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -809,15 +810,27 @@ __device__ __forceinline__ void carry_history(const FftArgs& a, const float* old
 // finishes last leaves the handle's device state ready for the next launch on the stream: ticket
 // counters back to zero, history buffers swapped.  Nothing of this is host state, so a captured
 // graph of one call replays as the stream's next call (tests/test_graph_capture_gpu.py).
-__device__ __forceinline__ void call_done(const FftArgs& a, const unsigned cur) {
+// What it needs -- the state and ticket pointers -- it reads again from the kernel-argument segment through a
+// pointer the compiler cannot see through, instead of taking the caller's copies: values kept alive across the
+// persistent tile loop for this epilogue cost that loop scalar registers it does not have (it then re-loaded
+// `channels` from the argument segment in every tile, behind an s_waitcnt that also waits for the LDS: C2
+// 0.771 -> 0.798 ms, profiles/r03_device_state_ab.txt).  The kernels take FftArgs as their only parameter.
+__device__ __forceinline__ void call_done() {
     __syncthreads(); // every wave of the workgroup is past its reads of the state, the history and its tickets
-    if (last_workgroup_done(a.state, gridDim.x)) {
-        if (a.tickets) {
+    if (threadIdx.x == 0) {
+        const char __attribute__((address_space(4)))* ka =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        FirDevState* const st = *reinterpret_cast<FirDevState* const __attribute__((address_space(4)))*>(ka + offsetof(FftArgs, state));
+        if (last_workgroup_done(st, gridDim.x)) {
+            unsigned* const tickets = *reinterpret_cast<unsigned* const __attribute__((address_space(4)))*>(ka + offsetof(FftArgs, tickets));
+            if (tickets) {
 #pragma unroll
-            for (int t = 0; t < FFT_TICKETS; ++t) a.tickets[FFT_TICKET_STRIDE * t] = 0;
+                for (int t = 0; t < FFT_TICKETS; ++t) tickets[FFT_TICKET_STRIDE * t] = 0;
+            }
+            st->done = 0;
+            st->cur = (st->cur & 1u) ^ 1u; // unchanged since the launch began: only this workgroup, here, writes it
         }
-        a.state->done = 0;
-        a.state->cur = cur ^ 1u;
     }
 }
 
@@ -839,20 +852,25 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     // (the uncached partitioned variants keep their short work in a launch of its own, fir_fft4096_short,
     // which also ends the call; their interior workgroups touch neither history nor state)
     if constexpr (ONE_LAUNCH) {
-        const unsigned cur = a.state->cur & 1u;
         if (bid < a.grid_carry) {
-            carry_history<GEN>(a, a.hist[cur], a.hist[cur ^ 1u], REAL ? 1 : 2, bid, a.grid_carry);
-        } else if (bid < a.grid_carry + a.grid_edge) {
-            c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
-            edge_tiles<REAL, GEN>(a, a.hist[cur], lds, c, bid - a.grid_carry, a.grid_edge);
-        } else {
-            interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid - a.grid_carry - a.grid_edge,
-                                                            (int)gridDim.x - a.grid_carry - a.grid_edge);
+            const unsigned cur = a.state->cur & 1u;
+            carry_history<GEN>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, bid, a.grid_carry);
+            call_done();
+            return;
         }
-        call_done(a, cur);
-    } else {
-        interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid, (int)gridDim.x);
+        bid -= a.grid_carry;
+        if (bid < a.grid_edge) {
+            const unsigned cur = a.state->cur & 1u;
+            c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
+            edge_tiles<REAL, GEN>(a, pick(a.hist, cur), lds, c, bid, a.grid_edge);
+            call_done();
+            return;
+        }
+        bid -= a.grid_edge;
     }
+    interior_tiles<REAL, HQ, LONG, TBL, CACHE, GEN>(a, lds, c, bid,
+                                                    ONE_LAUNCH ? (int)gridDim.x - a.grid_carry - a.grid_edge : (int)gridDim.x);
+    if constexpr (ONE_LAUNCH) call_done(); // (interior workgroups touch neither history nor state before this)
 }
 
 // carry + edge workgroups alone (partitioned filters; calls without interior tiles)
@@ -864,13 +882,13 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
     // always carried) and ends the call: its last workgroup zeroes the main launch's tickets and swaps the histories
     const unsigned cur = a.state->cur & 1u;
     if (bid < a.grid_carry) {
-        carry_history<GEN>(a, a.hist[cur], a.hist[cur ^ 1u], REAL ? 1 : 2, bid, a.grid_carry);
+        carry_history<GEN>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, bid, a.grid_carry);
     } else {
         LaneConstsT<true> c;
         c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, lds + 16 * ROW);
-        edge_tiles<REAL, GEN>(a, a.hist[cur], lds, c, bid - a.grid_carry, a.grid_edge);
+        edge_tiles<REAL, GEN>(a, pick(a.hist, cur), lds, c, bid - a.grid_carry, a.grid_edge);
     }
-    call_done(a, cur);
+    call_done();
 }
 
 template <bool REAL, bool GEN>

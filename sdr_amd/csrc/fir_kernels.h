@@ -22,8 +22,17 @@ struct FirDevState {
 // `nblk` of them, behind a barrier that every wave reaches after its last read of *st).
 __device__ __forceinline__ bool last_workgroup_done(FirDevState* st, unsigned nblk) {
     if (threadIdx.x != 0) return false;
-    return __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == nblk;
+    // Relaxed on purpose.  What must precede the flip is every workgroup's READ of the state, and that is
+    // program order (the value was used before the barrier); what the winner writes is first read by the NEXT
+    // launch on the stream, and the kernel boundary orders that.  An acq_rel atomic here costs every workgroup
+    // an L2 write-back (buffer_wbl2) at its end: C2 0.771 -> 0.798 ms, profiles/r03_device_state_ab.txt.
+    return __hip_atomic_fetch_add(&st->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nblk;
 }
+
+// the history buffer state->cur names / the other one, without indexing the kernel-argument struct by a run-time
+// value (that keeps the compiler from holding the arguments in registers: it reloads them at every use)
+template <class P>
+__device__ __forceinline__ P pick(P const (&h)[2], unsigned cur) { return cur ? h[1] : h[0]; }
 
 struct FirArgs {
     const float* in;      // channel 0, sample 0

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void fir_direct(FirArgs a) {
 
     Stream<REAL ? 1 : 2> src;
     src.in = a.in + ch * a.in_stride * (REAL ? 1 : 2);
-    src.hist = a.hist[a.state ? a.state->cur & 1u : 0u] + ch * (long long)a.hist_len * (REAL ? 1 : 2);
+    src.hist = pick(a.hist, a.state ? a.state->cur & 1u : 0u) + ch * (long long)a.hist_len * (REAL ? 1 : 2);
     src.n = a.n;
     src.hist_len = a.hist_len;
     src.vec_ok = a.vec_in;

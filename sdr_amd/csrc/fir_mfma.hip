@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, mfma_waves(SMAX)) void fir_mfma(MfmaArgs a) {
 
     MStream<W> src;
     src.in = a.in + ch * a.in_stride * W;
-    src.hist = a.hist[a.state ? a.state->cur & 1u : 0u] + ch * (long long)a.hist_len * W;
+    src.hist = pick(a.hist, a.state ? a.state->cur & 1u : 0u) + ch * (long long)a.hist_len * W;
     src.n = a.n;
     src.hist_len = a.hist_len;
     src.vec_ok = a.vec_in;
