@@ -37,14 +37,8 @@
 #include <stdlib.h>
 
 #include "fir_kernels.h"
+#include "fft_math.h"
 
-// cache policy of the streaming loads / stores (experiments: -DSDR_LD_NT=0 / -DSDR_ST_NT=0)
-#ifndef SDR_LD_NT
-#define SDR_LD_NT 1
-#endif
-#ifndef SDR_ST_NT
-#define SDR_ST_NT 1
-#endif
 // shares the next tile's 16 row loads are issued in: 0 = one burst, 1 = three, 2 = six, 3 = eight
 #ifndef SDR_SPREAD
 #define SDR_SPREAD 2
@@ -109,78 +103,13 @@
 #define SDR_CONTIG(a) 0
 #endif
 namespace sdr_amd {
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <class T>
-__device__ __forceinline__ T stream_load(const T* p) {
-#if SDR_LD_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-template <class T>
-__device__ __forceinline__ void stream_store(T v, T* p) {
-#if SDR_ST_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-
 namespace {
 
 constexpr int FFT_N = 4096;
 constexpr int ROW = 272; // complex elements per k0 row in LDS (256 + 16 pad)
 
-// a + (-i) b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ f2 add_mi(f2 a, f2 b) {
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a + (+i) b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ f2 add_pi(f2 a, f2 b) {
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// x * w : two packed ops (broadcast / swap / negate are operand modifiers)
-__device__ __forceinline__ f2 cmul(f2 x, f2 w) {
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
-    return r;
-}
-// x * conj(w)
-__device__ __forceinline__ f2 cmulc(f2 x, f2 w) {
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
-    return r;
-}
-// x * (c, s) with a compile-time constant held in an SGPR pair
-__device__ __forceinline__ f2 cmul_k(f2 x, float c, float s) {
-    const f2 w = {c, s};
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "s"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "s"(w), "v"(t));
-    return r;
-}
-
-template <bool INV>
-__device__ __forceinline__ void radix4(f2& x0, f2& x1, f2& x2, f2& x3) {
-    const f2 s0 = x0 + x2, s1 = x0 - x2, s2 = x1 + x3, s3 = x1 - x3;
-    x0 = s0 + s2;
-    x2 = s0 - s2;
-    if (!INV) { x1 = add_mi(s1, s3); x3 = add_pi(s1, s3); }
-    else      { x1 = add_pi(s1, s3); x3 = add_mi(s1, s3); }
-}
-
 // In-place 16-point DFT (INV: inverse, unscaled).  Input v[n] in natural order;
 // output X[k] is left at v[P16(k)], P16(k) = 4*(k&3) + (k>>2).
-template <int V> struct IC { static constexpr int value = V; };
 __host__ __device__ constexpr int P16(int k) { return 4 * (k & 3) + (k >> 2); }
 
 template <bool INV>
@@ -268,7 +197,6 @@ struct LaneConstsT {
 // everyone must be done before this one writes.  After an INVERSE transform no barrier is
 // needed here: past its block barrier every wave only reads its own columns (stage A'),
 // and the writes below touch only the writer's own columns.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <class Consts, class Hook, class HookB = NoHook, class HookR = NoHook>
 __device__ __forceinline__ void forward_tile(f2 (&v)[16], f2* lds, int tid, const Consts& c, Hook&& after_points_left,
                                              bool after_forward = false, HookB&& after_stage_b = HookB{},
