@@ -310,9 +310,24 @@ __device__ __forceinline__ f2 spectrum(const float* hperm, int p, int k2, int ti
 // generator's recipe (gen_device.h) instead of being loaded -- the fused
 // gen -> hilbert -> FIR chain writes 4 bytes per sample and reads none.
 // Workgroup `bid` of `nblk` interior workgroups.
-template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
-__device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneConstsT<TBL, GEN ? SDR_TW_BATCH : 1>& c, const int bid,
+template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, int GEN>
+__device__ __forceinline__ void interior_tiles(const FftArgs& a0, f2* lds, LaneConstsT<TBL, GEN ? SDR_TW_BATCH : 1>& c, const int bid,
                                                const int nblk) {
+    // The persistent loop is short of scalar registers, and the compiler's way out is to re-load a kernel argument
+    // from the argument segment wherever it is used -- inside the tile loop, behind an s_waitcnt lgkmcnt(0) that
+    // also drains the wave's LDS reads (3.5 % of C2 when it happened to `channels`, profiles/r03_device_state_ab.txt;
+    // which argument it picks changes with any edit of FftArgs).  The arguments the loop uses are copied once and
+    // made opaque: the copies live in registers (or VGPR lanes), never behind a load.  `make asm` +
+    // scripts/asm_loops.py lists the scalar loads inside every loop of a kernel: check it after touching FftArgs.
+    // Only where it happens -- the fused-generator kernels: the others keep their arguments in registers by
+    // themselves, and the copies cost them 2.5 % (the allocator then spills other values to VGPR lanes).
+    FftArgs al = a0;
+    if constexpr (GEN != 0) {
+        asm volatile("" : "+s"(al.out), "+s"(al.out_stride), "+s"(al.channels), "+s"(al.t_lo), "+s"(al.t_hi), "+s"(al.tickets));
+        asm volatile("" : "+s"(al.gen.phi), "+s"(al.gen.phi_incr), "+s"(al.gen.amp), "+s"(al.gen.cps), "+s"(al.gen.pincr));
+    }
+    if constexpr (GEN == 0 && REAL) asm volatile("" : "+s"(al.in_stride), "+s"(al.channels)); // (the two it re-loads there)
+    const FftArgs& a = (GEN != 0 || REAL) ? al : a0;
     static_assert(!LONG || HQ == 32, "partitioned mode uses hop 2048");
     static_assert(HQ >= 1 && HQ <= 32 && (HQ & (HQ - 1)) == 0, "halo = 64 * {1,2,4,8,16,32}");
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
@@ -396,12 +411,18 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a, f2* lds, LaneCo
         return Cursor{b, (int)r};
     };
     const Cursor genD = GEN ? cursor_at(D) : Cursor{0, 0}; // the im member runs D samples ahead of the re member
+    // closed-form phases (GenSrc::pstate): the generator's position, read once per workgroup
+    // (GEN = 2, a kernel of its own: as a run-time choice the two phase sources cost the persistent loop scalar
+    // registers it does not have -- it re-loaded kernel arguments in every tile)
+    constexpr bool gen_closed = GEN == 2;
+    const unsigned genP0 = gen_closed ? a.gen.pstate->phase : 0u;
     auto walk_open = [&](Cursor c, Walk& s) __attribute__((always_inline)) {
         int i = c.rb + tid;
         const bool wrap = i >= genB;
         i = wrap ? i - genB : i;
         s.idx = (float)i;
-        s.p = a.gen.phi[(unsigned)c.b + (wrap ? 1u : 0u)];
+        const unsigned blk = (unsigned)c.b + (wrap ? 1u : 0u);
+        s.p = gen_closed ? gen_phase_closed(genP0, a.gen.pincr, blk) : a.gen.phi[blk];
         s.base = s.p + gen_quarter;
     };
     auto gen_open = [&](long long o, Walk& s0, Walk& s1) __attribute__((always_inline)) {
@@ -758,6 +779,16 @@ __device__ __forceinline__ void call_done() {
             }
             st->done = 0;
             st->cur = (st->cur & 1u) ^ 1u; // unchanged since the launch began: only this workgroup, here, writes it
+            // a fused generator with closed-form phases moves on by this call's blocks (GenSrc::pstate)
+            GenDevState* const gs = *reinterpret_cast<GenDevState* const __attribute__((address_space(4)))*>(
+                ka + offsetof(FftArgs, gen) + offsetof(GenSrc, pstate));
+            if (gs) {
+                const unsigned pincr = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(
+                    ka + offsetof(FftArgs, gen) + offsetof(GenSrc, pincr));
+                const unsigned nblocks = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(
+                    ka + offsetof(FftArgs, gen) + offsetof(GenSrc, nblocks));
+                gs->phase = (gs->phase + nblocks * pincr) & 0x7fffffu;
+            }
         }
     }
 }
@@ -766,7 +797,7 @@ __device__ __forceinline__ void call_done() {
 // next a.grid_edge take the edge tiles, the rest are the persistent interior
 // workgroups: the few slow, bounds-checked tiles start first and overlap the bulk
 // instead of trailing it as separate launches.
-template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, bool GEN>
+template <bool REAL, int HQ, bool LONG, bool TBL, bool CACHE, int GEN>
 __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftArgs a) {
     // (padding the LDS to a third of the CU -- which in the copy skeletons moves 4 % more bytes, because 54 KB
     // workgroups end up TWO per CU and fewer bytes in flight suit the memory system -- costs this kernel 3.5 %:
@@ -782,7 +813,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
     if constexpr (ONE_LAUNCH) {
         if (bid < a.grid_carry) {
             const unsigned cur = a.state->cur & 1u;
-            carry_history<GEN>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, bid, a.grid_carry);
+            carry_history<GEN != 0>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, bid, a.grid_carry);
             call_done();
             return;
         }
@@ -790,7 +821,7 @@ __global__ __launch_bounds__(256, (TBL && !LONG) ? 3 : 2) void fir_fft4096(FftAr
         if (bid < a.grid_edge) {
             const unsigned cur = a.state->cur & 1u;
             c.init(threadIdx.x, a.hperm, false, reinterpret_cast<const f2*>(a.wtab), lds, TBL ? lds + 16 * ROW : nullptr);
-            edge_tiles<REAL, GEN>(a, pick(a.hist, cur), lds, c, bid, a.grid_edge);
+            edge_tiles<REAL, GEN != 0>(a, pick(a.hist, cur), lds, c, bid, a.grid_edge);
             call_done();
             return;
         }
@@ -819,7 +850,8 @@ __global__ __launch_bounds__(256, 2) void fir_fft4096_short(FftArgs a) {
     call_done();
 }
 
-template <bool REAL, bool GEN>
+// GEN: 0 = samples are loaded, 1 = synthesised with the host's phase table, 2 = with closed-form phases (GenSrc::pstate)
+template <bool REAL, int GEN>
 static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t stream) {
     const dim3 b(256);
     const int n_short = a.grid_carry + a.grid_edge;
@@ -835,7 +867,7 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
         }
         // (forking this short launch onto a side stream so that it runs beside the main kernel was
         // tried: the two event hand-offs cost more than the 17 us it hides, C3 0.456 -> 0.480 ms)
-        if (n_short > 0) hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN>), dim3((unsigned)n_short), b, 0, stream, a);
+        if (n_short > 0) hipLaunchKernelGGL((fir_fft4096_short<REAL, GEN != 0>), dim3((unsigned)n_short), b, 0, stream, a);
         return hipGetLastError();
     }
     const dim3 g((unsigned)(grid_int + n_short));
@@ -905,8 +937,8 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     a.grid_edge = (int)(edge < grid_blocks ? edge : grid_blocks);
     const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
     a.grid_carry = (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64); // >= 1: every call carries
-    if (a.gen.enabled) return launch_tiles<true, true>(a, grid_int, stream);
-    return real ? launch_tiles<true, false>(a, grid_int, stream) : launch_tiles<false, false>(a, grid_int, stream);
+    if (a.gen.enabled) return a.gen.pstate ? launch_tiles<true, 2>(a, grid_int, stream) : launch_tiles<true, 1>(a, grid_int, stream);
+    return real ? launch_tiles<true, 0>(a, grid_int, stream) : launch_tiles<false, 0>(a, grid_int, stream);
 }
 
 const char* fir_fft_kernel_name(bool real) { return real ? "fir_fft4096<REAL>" : "fir_fft4096<COMPLEX>"; }

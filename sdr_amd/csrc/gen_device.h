@@ -18,8 +18,21 @@
 namespace sdr_amd {
 
 // Generator as an input source of a FIR kernel (real samples only).
+// Where the generator stands, in DEVICE memory, when its phase recurrence has a closed form (sdr_capi.hip,
+// phase_chain_is_exact: phase and increment whole multiples of 2^-23, so no step of phi' = fract(phi + incr)
+// ever rounds): the next block's start phase in units of 2^-23.  Kernels read it, the last workgroup of a call
+// moves it on -- nothing about the generator's position is host state then, so a captured graph of one
+// generating call replays as the stream's next call.
+struct GenDevState {
+    unsigned phase; // P: the next block starts at phase P / 2^23
+    unsigned done;  // stand-alone generator kernel: workgroups of the running launch that have finished
+};
+
 struct GenSrc {
-    const float* phi;     // start phase of blocks 0..blocks of this call (one spare entry at the end)
+    const float* phi;     // start phase of blocks 0..blocks of this call (one spare entry at the end); unused with pstate
+    GenDevState* pstate;  // non-NULL: block b of this call starts at phase ((pstate->phase + b * pincr) mod 2^23) / 2^23
+    unsigned pincr;       // the per-block increment in units of 2^-23
+    unsigned nblocks;     // blocks of this call: what the call's last workgroup advances pstate->phase by
     float phi_incr;       // phase advance per block, in [0, 1): phi[k+1] = phi[k] + phi_incr, less 1 if >= 1 (fp32)
     long long block_size; // B, 256 <= B <= 2^23
     double inv_block;     // 1.0 / B
@@ -134,6 +147,16 @@ __device__ __forceinline__ gen_f2 gen_sine_pair(float amp, float cps, gen_f2 bas
     return r * -amp;
 }
 
+// Start phase of block b of the call: exact integer arithmetic (every multiple of 2^-23 below 1 is a float, and
+// the scaling by a power of two is exact) or the host's table -- the same bits either way.
+__device__ __forceinline__ float gen_phase_closed(unsigned P0, unsigned pincr, unsigned b) {
+    return (float)((P0 + b * pincr) & 0x7fffffu) * (1.0f / 8388608.0f);
+}
+__device__ __forceinline__ float gen_phase(const GenSrc& g, unsigned b) {
+    if (g.pstate) return gen_phase_closed(g.pstate->phase, g.pincr, b);
+    return g.phi[b];
+}
+
 // Sample m (>= 0, counted from the first sample of the call) of a generator source:
 // block m / B, index m % B.  The quotient comes from a double multiply with one
 // correction step (m < 2^52).
@@ -142,7 +165,7 @@ __device__ __forceinline__ float gen_src_at(const GenSrc& g, long long m) {
     long long r = m - b * g.block_size;
     if (r < 0) { r += g.block_size; --b; }
     else if (r >= g.block_size) { r -= g.block_size; ++b; }
-    return gen_real_sample(g.waveform, g.amp, g.cps, g.phi[b], (int)r);
+    return gen_real_sample(g.waveform, g.amp, g.cps, gen_phase(g, (unsigned)b), (int)r);
 }
 
 } // namespace sdr_amd

@@ -2,11 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gen_device.h"
+
 namespace sdr_amd {
 
 struct GenArgs {
     float* out;        // blocks*block_size samples (complex: float pairs)
-    const float* phi;  // per-block start phase, cycles in [0,1)
+    const float* phi;  // per-block start phase, cycles in [0,1); unused with pstate
+    GenDevState* pstate; // non-NULL: closed-form phases from the device's own position (gen_device.h), moved on
+    unsigned pincr;      // by `blocks` blocks when the launch's last workgroup finishes
     long long blocks;
     long long block_size;
     float amp;

@@ -28,9 +28,9 @@ namespace sdr_amd {
 // division on the per-sample path, coalesced 4/8-byte stores.
 __global__ __launch_bounds__(256) void gen_blocks(GenArgs a) {
     const int i = blockIdx.y * 256 + threadIdx.x;
-    if (i >= a.block_size) return;
-    for (long long b = blockIdx.x; b < a.blocks; b += gridDim.x) {
-        const float phi = a.phi[b];
+    const unsigned P0 = a.pstate ? a.pstate->phase : 0u;
+    for (long long b = blockIdx.x; i < a.block_size && b < a.blocks; b += gridDim.x) {
+        const float phi = a.pstate ? gen_phase_closed(P0, a.pincr, (unsigned)b) : a.phi[b];
         const float step = __fmul_rn(a.cps, (float)i);
         const long long s = b * a.block_size + i;
         if (!a.complex_samples) {
@@ -41,6 +41,15 @@ __global__ __launch_bounds__(256) void gen_blocks(GenArgs a) {
             float sn, cs;
             sincosf(ang, &sn, &cs);
             reinterpret_cast<float2*>(a.out)[s] = make_float2(__fmul_rn(a.amp, cs), __fmul_rn(a.amp, sn));
+        }
+    }
+    if (a.pstate) {
+        // the launch's last workgroup to finish moves the generator on (every wave has read the phase by now)
+        __syncthreads();
+        if (threadIdx.x == 0 &&
+            __hip_atomic_fetch_add(&a.pstate->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x * gridDim.y) {
+            a.pstate->done = 0;
+            a.pstate->phase = (P0 + (unsigned)a.blocks * a.pincr) & 0x7fffffu;
         }
     }
 }

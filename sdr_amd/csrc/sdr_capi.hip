@@ -661,6 +661,14 @@ struct sdr_gen {
     int next_table = 0;
     float* d_out = nullptr; // staging for the host entry point
     size_t out_cap = 0;
+    // Closed-form phase chain (phase_chain_is_exact): the generator's position lives in DEVICE memory and the
+    // kernels move it on themselves -- no per-call phase table, nothing of the position on the host, so a captured
+    // graph of one generating call replays as the next call.  dev_phase: d_state->phase, not `phi`, is the truth.
+    GenDevState* d_state = nullptr;
+    bool dev_phase = false;
+    unsigned pincr = 0;          // phi_incr in units of 2^-23 (dev_phase)
+    hipEvent_t last = nullptr;   // behind the latest generating launch (what to_host waits for)
+    bool have_last = false;
     // complex square / triangle / sawtooth (blocks/gen.cpp:138, 147-164, 231-260): the
     // waveform plus +-j times its Hilbert transform from a real FIR
     size_t hilbert_taps = 127;
@@ -673,6 +681,38 @@ struct sdr_gen {
 };
 
 static inline float fractf_host(float x) { return x - floorf(x); }
+
+static bool phase_chain_is_exact(float phi, float incr, unsigned* P, unsigned* I);
+
+// Move the generator's position to the device when its phase chain has a closed form (not for the quadrature
+// waveforms, whose second table is built on the host), or back to the host (for a change of frequency, an
+// advance, or a chain that stops being exact).  to_host waits for the latest generating launch the library
+// itself queued; replays of a captured graph are the caller's to finish first.
+static int gen_to_device(sdr_gen* g) {
+    unsigned P, I;
+    if (g->dev_phase || g->quadrature() || !phase_chain_is_exact(g->phi, g->phi_incr, &P, &I)) return SDR_OK;
+    GenDevState st = {P, 0u};
+    SDR_HIP(hipMemcpy(g->d_state, &st, sizeof st, hipMemcpyHostToDevice));
+    g->pincr = I;
+    g->dev_phase = true;
+    return SDR_OK;
+}
+static int gen_to_host(sdr_gen* g) {
+    if (!g->dev_phase) return SDR_OK;
+    if (g->have_last) SDR_HIP(hipEventSynchronize(g->last));
+    GenDevState st;
+    SDR_HIP(hipMemcpy(&st, g->d_state, sizeof st, hipMemcpyDeviceToHost));
+    g->phi = (float)(st.phase & 0x7fffffu) * (1.0f / 8388608.0f);
+    g->dev_phase = false;
+    return SDR_OK;
+}
+// after a generating launch on `stream`
+static int gen_mark_launch(sdr_gen* g, hipStream_t stream) {
+    if (stream_is_capturing(stream)) return SDR_OK; // a captured launch runs later, at the caller's command
+    SDR_HIP(hipEventRecord(g->last, stream));
+    g->have_last = true;
+    return SDR_OK;
+}
 
 extern "C" size_t sdr_optimal_block_size(uint64_t element_size, uint64_t sample_rate) {
     if (element_size == 0) return 0;
@@ -716,6 +756,10 @@ extern "C" int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, fl
         if (e == hipSuccess) e = hipEventCreateWithFlags(&t.free, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->last, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&g->d_state, 256);
+    if (e == hipSuccess) e = hipMemset(g->d_state, 0, 256);
+    if (e == hipSuccess && gen_to_device(g) != SDR_OK) e = hipErrorUnknown;
     if (e != hipSuccess) {
         int rc = hip_fail(e, "sdr_gen_create");
         std::string keep = g_last_error;
@@ -730,9 +774,12 @@ extern "C" int sdr_gen_create(sdr_gen_t** out, int waveform, int sample_kind, fl
 extern "C" int sdr_gen_set_frequency(sdr_gen_t* g, float cycles_per_sample) {
     clear_error();
     if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_set_frequency: NULL handle");
+    DeviceGuard guard(g->device);
+    int rc = gen_to_host(g);
+    if (rc != SDR_OK) return rc;
     g->cps = cycles_per_sample;
     g->phi_incr = fractf_host(cycles_per_sample * (float)g->block_size);
-    return SDR_OK;
+    return gen_to_device(g);
 }
 
 // The per-block phase recurrence phi' = fract(phi + incr) in fp32 is a serial chain (~3 ns per block on the host:
@@ -756,6 +803,9 @@ extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
     if (!g) return fail(SDR_ERR_INVALID, "sdr_gen_advance: NULL handle");
     if (g->quadrature() && blocks)
         return fail(SDR_ERR_INVALID, "sdr_gen_advance: a quadrature generator carries a filter history that cannot be skipped");
+    DeviceGuard guard(g->device);
+    int rc = gen_to_host(g);
+    if (rc != SDR_OK) return rc;
     float phi = g->phi;
     const float incr = g->phi_incr;
     unsigned P, I;
@@ -765,7 +815,7 @@ extern "C" int sdr_gen_advance(sdr_gen_t* g, size_t blocks) {
         for (size_t b = 0; b < blocks; ++b) phi = fractf_host(phi + incr);
     }
     g->phi = phi;
-    return SDR_OK;
+    return gen_to_device(g);
 }
 
 // The next `blocks` per-block start phases (plus one spare entry, read but never used
@@ -832,18 +882,29 @@ static int gen_quadrature_impl(sdr_gen* g, size_t blocks, float* d_out, hipStrea
 static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
     if (blocks == 0) return SDR_OK;
     if (g->quadrature()) return gen_quadrature_impl(g, blocks, d_out, stream);
-    sdr_gen::Table* t = nullptr;
-    int rc = gen_next_table(g, blocks, stream, &t);
-    if (rc != SDR_OK) return rc;
+    if (blocks > 0xffffffffull) return fail(SDR_ERR_INVALID, "generator: more than 2^32 - 1 blocks in one call");
     GenArgs a;
     a.out = d_out;
-    a.phi = t->d;
     a.blocks = (long long)blocks;
     a.block_size = (long long)g->block_size;
     a.amp = g->amp;
     a.cps = g->cps;
     a.waveform = g->waveform;
     a.complex_samples = g->kind == SDR_COMPLEX;
+    if (g->dev_phase) {
+        // closed-form phases from the device's own position: no table, nothing of this call's position on the host
+        a.phi = nullptr;
+        a.pstate = g->d_state;
+        a.pincr = g->pincr;
+        SDR_HIP(launch_gen(a, stream));
+        return gen_mark_launch(g, stream);
+    }
+    sdr_gen::Table* t = nullptr;
+    int rc = gen_next_table(g, blocks, stream, &t);
+    if (rc != SDR_OK) return rc;
+    a.pstate = nullptr;
+    a.pincr = 0;
+    a.phi = t->d;
     SDR_HIP(launch_gen(a, stream));
     SDR_HIP(hipEventRecord(t->free, stream));
     return SDR_OK;
@@ -855,6 +916,9 @@ static int gen_device_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t 
 // hilb = real FIR with sdr::hilbert taps whose history runs on from block to block (and from
 // the pre-roll, :147-164).  Two generator launches, one pass of the FIR path, one interleave.
 static int gen_quadrature_impl(sdr_gen* g, size_t blocks, float* d_out, hipStream_t stream) {
+    if (stream_is_capturing(stream))
+        return fail(SDR_ERR_INVALID, "generator: the quadrature waveforms (complex square / triangle / sawtooth) build per-call "
+                                     "phase tables on the host and cannot be recorded into a HIP graph");
     const size_t n = blocks * g->block_size;
     const size_t hd = (g->hilbert_taps - 1) / 2;
     if (!g->quad) {
@@ -876,6 +940,8 @@ static int gen_quadrature_impl(sdr_gen* g, size_t blocks, float* d_out, hipStrea
         g->quad_cap = cap;
     }
     GenArgs a;
+    a.pstate = nullptr; // the quadrature path keeps its position on the host (its second table is built there)
+    a.pincr = 0;
     a.amp = 1.0f;
     a.cps = g->cps;
     a.waveform = g->waveform;
@@ -949,10 +1015,13 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     if (blocks == 0) return SDR_OK;
     DeviceGuard guard(f->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    if (blocks > 0xffffffffull) return fail(SDR_ERR_INVALID, "fused generator: more than 2^32 - 1 blocks in one call");
     sdr_gen::Table* t = nullptr;
     const float incr = g->phi_incr; // of this call's blocks
-    rc = gen_next_table(g, blocks, stream, &t);
-    if (rc != SDR_OK) return rc;
+    if (!g->dev_phase) {
+        rc = gen_next_table(g, blocks, stream, &t);
+        if (rc != SDR_OK) return rc;
+    }
     FftArgs fa = {};
     fa.in = nullptr;
     fa.out = d_out;
@@ -963,7 +1032,10 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.halo = f->fft_halo;
     fa.hist_len = f->hist_len;
     fa.parts = f->fft_parts;
-    fa.gen.phi = t->d;
+    fa.gen.phi = t ? t->d : nullptr;
+    fa.gen.pstate = g->dev_phase ? g->d_state : nullptr;
+    fa.gen.pincr = g->pincr;
+    fa.gen.nblocks = (unsigned)blocks;
     fa.gen.phi_incr = incr;
     fa.gen.block_size = (long long)g->block_size;
     fa.gen.inv_block = 1.0 / (double)g->block_size;
@@ -973,7 +1045,8 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.gen.enabled = 1;
     fft_common_args(f, fa);
     SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
-    SDR_HIP(hipEventRecord(t->free, stream));
+    if (t) SDR_HIP(hipEventRecord(t->free, stream));
+    else return gen_mark_launch(g, stream);
     return SDR_OK;
 }
 
@@ -1020,6 +1093,8 @@ extern "C" void sdr_gen_destroy(sdr_gen_t* g) {
         if (t.ready) (void)hipEventDestroy(t.ready);
     }
     if (g->d_out) (void)hipFree(g->d_out);
+    if (g->d_state) (void)hipFree(g->d_state);
+    if (g->last) (void)hipEventDestroy(g->last);
     for (float* p : g->d_quad)
         if (p) (void)hipFree(p);
     if (g->quad) sdr_fir_destroy(g->quad);

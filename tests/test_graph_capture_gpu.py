@@ -163,3 +163,90 @@ def test_chain_call_past_the_start_of_the_stream_is_capturable_and_the_start_is_
         got.append(d_out.cpu().numpy().copy())
     want = O.fir(lp, O.fir(h, x)[63:])
     assert rel_err(np.concatenate(got), want) <= TOL
+
+
+def staged(stages, x):
+    y = x
+    for taps, skip in stages:
+        y = O.fir(taps, y)[skip:]
+    return y
+
+
+@pytest.mark.parametrize("wf,phase", [("sine", 0.0), ("cosine", 90.0), ("triangle", 45.0)])
+def test_one_captured_fused_generator_call_replays_as_the_stream(wf, phase):
+    """ONE sdr_chain_generate_device (gen -> hilbert -> lowpass, samples synthesised inside the FIR kernel)
+    captured and replayed five times, an ordinary call in between: eight calls, one stream.  The generator's
+    position is device state when its phase recurrence has a closed form (phase and per-block increment whole
+    multiples of 2^-23: the usual case, here 0.1 cycles per sample in 2044-sample packets): the kernels compute
+    every block's start phase from it and the call's last workgroup moves it on."""
+    import torch
+    B = sdr_amd.optimal_block_size(4, 1000000)
+    cps = float(np.float32(100e3) / np.float32(1e6))
+    stages = [(sdr_amd.hilbert(127), 63), (sdr_amd.fir_lowpass(127, 0.12), 0)]
+    gen = sdr_amd.Gen(wf, False, 0.8, cps, phase, B)
+    chain = sdr_amd.Chain(stages, False)
+    nb = 40
+    out = torch.zeros(nb * B, dtype=torch.float32, device="cuda")
+    got = []
+    n0 = chain.generate_device(gen, 3, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)  # start of the stream
+    torch.cuda.synchronize()
+    got.append(out[:n0].cpu().numpy())
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        assert chain.generate_device(gen, nb, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream) == nb * B
+    blocks = 3
+    for step in (None, None, 7, None, None, None):
+        if step is None:
+            graph.replay()
+            torch.cuda.synchronize()
+            got.append(out.cpu().numpy().copy())
+            blocks += nb
+        else:
+            n1 = chain.generate_device(gen, step, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got.append(out[:n1].cpu().numpy())
+            blocks += step
+    x, _ = O.gen_real(blocks, B, 0.8, cps, float(np.float32(phase) / np.float32(360.0)), sdr_amd.WAVEFORMS[wf])
+    want = staged(stages, x)
+    y = np.concatenate(got)
+    assert y.shape == want.shape and rel_err(y, want) <= TOL
+
+
+def test_captured_generator_kernel_and_what_cannot_be_captured():
+    """sdr_gen_generate_device with a closed-form phase chain: one captured call replays as consecutive packets,
+    bit for bit the oracle's recipe.  A generator whose phase recurrence rounds (here 1e-5 cycles per sample: the
+    per-block increment is no multiple of 2^-23) needs its per-call phase table from the host: a capture is
+    refused with a message, and so is one of the quadrature waveforms."""
+    import torch
+    B = 2044
+    cps = float(np.float32(0.1))
+    gen = sdr_amd.Gen("sine", False, 1.0, cps, 45.0, B)   # 45 / 360 = 2^-3: a whole multiple of 2^-23 (30 degrees is not)
+    nb = 16
+    buf = torch.zeros(nb * B, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        gen.generate_device(nb, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    got = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        got.append(buf.cpu().numpy().copy())
+    got.append(gen.generate(5))   # the host entry point continues where the replays stopped
+    ref, _ = O.gen_real(3 * nb + 5, B, 1.0, cps, float(np.float32(45.0) / np.float32(360.0)), 1)
+    assert np.array_equal(np.concatenate(got), ref)
+
+    slow = sdr_amd.Gen("sine", False, 1.0, float(np.float32(1e-5)), 0.0, B)
+    quad = sdr_amd.Gen("square", True, 1.0, cps, 0.0, 1022)
+    cbuf = torch.zeros(2 * nb * B, dtype=torch.float32, device="cuda")
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=side):
+        buf.zero_()
+        with pytest.raises(sdr_amd.SdrError, match="HIP graph"):
+            slow.generate_device(nb, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(sdr_amd.SdrError, match="HIP graph"):
+            quad.generate_device(nb, cbuf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    # uncaptured, both work as ever
+    ref2, _ = O.gen_real(4, B, 1.0, float(np.float32(1e-5)), 0.0, 1)
+    assert np.array_equal(slow.generate(4), ref2)
