@@ -46,6 +46,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate
 USE_DIST = False          # set in main(): a torch.distributed process group is up
+RAMP_S = 0.2              # untimed clock-ramp prelude ahead of the warm-up steps (reported in the JSON line)
 
 WORKLOADS = {
     # name: (description, complex?, taps builder, log2 samples per channel, channels, scaling)
@@ -77,6 +78,9 @@ WORKLOADS = {
     # fused chains (sdr_chain_*): handled by bench_chain() below
     "c4chain": ("64 channels x 2^24 real samples sharded over the GPUs, hilbert(127, delay skip) + lowpass(127) "
                 "fused in one pass (BASELINE configs[3])", False, None, 24, 64, "strong"),
+    # BASELINE configs[0] as it is stated: the drop-in BLOCKS through a unix pipe (bench_pipe() below; not a kernel timing)
+    "c1pipe": ("gen sine -> hilbert (default taps), 2^24 float32 samples, through a unix pipe: blocks/bin/gen | head -c | "
+               "blocks/bin/hilbert, the reference's own blocks beside it (BASELINE configs[0])", False, None, 24, 1, "weak"),
     "c5": ("fused gen(sine) -> hilbert(127) -> lowpass(127): 2^29 real outputs per GPU, samples synthesised inside "
            "the FIR kernel (BASELINE configs[4], per-GPU share)", False, None, 29, 1, "weak"),
 }
@@ -138,8 +142,11 @@ def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
             if my_ch:
                 chain.process_tensor(x, y)
 
-        def gather():
-            return sharding.gather_chunks(y[:my_ch], dist, dst=0)
+        def gather(transport, _plan=[]):
+            if not _plan:   # built once from the channel plan: sizes are known, the destination is allocated here
+                _plan.append(sharding.GatherPlan([c for _, c in sharding.plan_channels(channels, world)], (n,),
+                                                 torch.float32, dev, dist, dst=0))
+            return _plan[0].run(y[:my_ch], transport)
         bytes_per_step = n * my_ch * 8
         units = n * my_ch
         total_units = n * channels
@@ -184,6 +191,61 @@ def bench_chain(args, S, torch, dist, rank, local_rank, world, dev):
     return dict(step=step, units=units, total_units=total_units, step_bytes=bytes_per_step, kernel=name, ntaps=253,
                 desc=desc, kind="float32", channels=channels, scaling=scaling, flops_per_sample=flops, gather=gather,
                 cpu_spec=("chain", [t for t, _ in stages], False, min(args.cpu_log2n, 26)))
+
+
+def bench_pipe(args):
+    """BASELINE configs[0] end to end, reproducible from one command: `gen freq=100k waveform=sine sample_rate=1M
+    mode=real | head -c | hilbert > /dev/null` with the drop-in blocks (blocks/bin: two processes, each starting a
+    HIP runtime, packets over a pipe, PCIe both ways), and the reference's own blocks (oracle/_ref, built from
+    /root/reference in the build container) beside it in the same run.  `value` here is pipe-, PCIe- and
+    process-start-inclusive -- NOT the in-memory value of the other workloads -- and says so."""
+    log2n = WORKLOADS["c1pipe"][3]
+    B = 2044
+    packets = -(-(1 << log2n) // B)
+    nbytes = packets * (16 + 4 * B)
+    nsamp = packets * B
+    BIN, REF = os.path.join(ROOT, "blocks", "bin"), os.path.join(ROOT, "oracle", "_ref")
+    gen_args = "freq=100k waveform=sine sample_rate=1M mode=real"
+    for exe in ("gen", "hilbert"):
+        if not os.path.exists(os.path.join(BIN, exe)):
+            raise SystemExit("bench.py --workload c1pipe: blocks/bin/%s is not built (make -C blocks)" % exe)
+
+    def sh(cmd):
+        t0 = time.perf_counter()
+        subprocess.run(cmd, shell=True, check=True, executable="/bin/bash", stdout=subprocess.DEVNULL)
+        return time.perf_counter() - t0
+
+    def pipe(d):
+        return "%s/gen %s | head -c %d | %s/hilbert > /dev/null" % (d, gen_args, nbytes, d)
+    for _ in range(max(1, args.warmup and 1)):
+        sh(pipe(BIN))                                             # image page-in, first GPU touch
+    steps = max(1, min(args.steps, 10))
+    ts = [sh(pipe(BIN)) for _ in range(steps)]
+    # what of that is start-up: the same two processes on ONE packet (HIP runtime start, handles, first launch)
+    one = 16 + 4 * B
+    t_start = min(sh("%s/gen %s | head -c %d | %s/hilbert > /dev/null" % (BIN, gen_args, one, BIN)) for _ in range(3))
+    t = float(np.median(ts))
+    out = {
+        "metric": "Msamples/s (gen | hilbert through a unix pipe: c1pipe)", "value": nsamp / t / 1e6, "unit": "Msamples/s",
+        "value_kind": "END TO END through unix pipes: process start, HIP start-up, packet framing and PCIe both ways included; "
+                      "not comparable with the in-memory workloads' value",
+        "n_gpus": 1, "steps": steps, "warmup": 1, "ramp_s": 0.0, "untimed_steps": 1, "ms_per_step": t * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": WORKLOADS["c1pipe"][0], "samples_per_gpu": nsamp, "packets": packets, "taps": 127,
+                   "sample_kind": "float32", "command": pipe("blocks/bin")},
+        "startup": {"seconds_one_packet": t_start, "share_of_step": t_start / t,
+                    "what": "the same pipeline on ONE 2044-sample packet: two process starts, two HIP runtime start-ups, "
+                            "filter set-up and the first launch"},
+        "roofline": None,
+    }
+    if not args.no_cpu_baseline and os.path.exists(os.path.join(REF, "hilbert")):
+        tr = float(np.median([sh(pipe(REF)) for _ in range(2)]))
+        out["cpu_baseline"] = {"value": nsamp / tr / 1e6, "unit": "Msamples/s", "cores": 2, "kind": "reference",
+                               "sample": "the whole workload: the reference's gen | head -c | hilbert (oracle/_ref, g++ -std=gnu++14 "
+                                         "-O3 -ffast-math -DNDEBUG), two single-threaded processes, same box, same run"}
+    else:
+        out["cpu_baseline"] = None
+    emit_json_line(out)
 
 
 def fill_counter_based(x, first_sample, seed=0x5D12):
@@ -300,6 +362,17 @@ def collect_traffic(workload, path):
             "written": total["WRITE_SIZE"]}
 
 
+def traffic_file_version(path):
+    """Which measurement a committed traffic file is: the commit that last touched it (when git is there), else its mtime."""
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", path], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return "commit " + r.stdout.strip()
+    except Exception:
+        pass
+    return "mtime " + time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
+
+
 _REAL_STDOUT = None
 
 
@@ -380,6 +453,11 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.workload == "c1pipe":
+        if args.gpus != 1:
+            raise SystemExit("--workload c1pipe is a one-GPU pipeline of processes")
+        bench_pipe(args)         # the blocks are processes of their own: this one never touches the GPU
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)   # does not return
     keep_stdout_for_the_json_line()
@@ -459,8 +537,11 @@ def main():
         if my_ch:
             st.process_tensor(xin, yout)  # launches on torch's current stream
 
-    def gather():
-        return sharding.gather_chunks(y[: my_ch * n], dist, dst=0)
+    def gather(transport, _plan=[]):
+        if not _plan:
+            _plan.append(sharding.GatherPlan([c * n for _, c in sharding.plan_channels(channels, world)], (w,),
+                                             torch.float32, dev, dist, dst=0))
+        return _plan[0].run(y[: my_ch * n], transport)
     nonzero = int(np.count_nonzero(taps)) if st.tap_stride == 2 else len(taps)
     run_and_report(args, torch, dist, rank, world, dev, dict(
         step=step, units=n * my_ch, total_units=total_units, step_bytes=n * my_ch * 4 * w * 2, kernel=st.kernel_name,
@@ -476,9 +557,11 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
     # its idle clocks before the W warm-up steps begin (the first ~20 launches after idle run 3-5 % slower; a
     # driver that asks for `--steps 20 --warmup 5` would otherwise time the ramp, not the kernel).
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.2:
+    ramp_steps = 0
+    while time.perf_counter() - t_ramp < RAMP_S:
         step()
         torch.cuda.synchronize()
+        ramp_steps += 1
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -507,25 +590,35 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
 
     # strong-scaling workloads: the same steps followed by the gather of every rank's outputs on
     # rank 0 (result collection only; SURVEY 8e asks for throughput with and without it)
-    with_gather = None
+    with_gather = {}
     if USE_DIST and wl.get("gather") is not None:
         gsteps = max(1, min(args.steps, 5)) if on_gpu else 1   # the gloo rehearsal moves GBs through host sockets
-        if rank == 0:
-            print("bench.py: timing %d step(s) with the gather of every rank's outputs" % gsteps, file=sys.stderr, flush=True)
-        if on_gpu:
-            wl["gather"]()                  # communicator / buffers warm
-        torch.cuda.synchronize()
-        dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(gsteps):
-            step()
-            wl["gather"]()
-        torch.cuda.synchronize()
-        dtg = time.perf_counter() - t1
-        dist.barrier()
-        t = torch.tensor([dtg], dtype=torch.float64, device=dev if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        with_gather = (float(t.item()) / gsteps, gsteps)
+        for transport in ("p2p", "gather"):
+            if rank == 0:
+                print("bench.py: timing %d step(s) + result collection on rank 0 (%s)" % (gsteps, transport), file=sys.stderr, flush=True)
+            try:
+                wl["gather"](transport)         # communicator warm, destination buffer allocated (once, by the plan)
+            except ValueError:                  # the rooted gather needs equal slices
+                continue
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(gsteps):
+                step()
+                wl["gather"](transport)
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - t1
+            dist.barrier()
+            t = torch.tensor([dtg], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            with_gather[transport] = (float(t.item()) / gsteps, gsteps)
+    # every rank's own device time per step: imbalance between GPUs shows here
+    per_rank_ms = [kern_ms_avg]
+    if USE_DIST:
+        t = torch.zeros(world, dtype=torch.float64, device=dev if on_gpu else "cpu")
+        t[rank] = kern_ms_avg
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(v) for v in t.tolist()]
 
     if rank == 0:
         units_all = wl["total_units"]
@@ -538,7 +631,8 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
         out = {
             "metric": "Msamples/s (FIR hot path: %s)" % args.workload,
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "warmup": args.warmup, "ramp_s": RAMP_S, "untimed_steps": ramp_steps + args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": wl["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "samples_per_gpu": wl["units"], "channels": wl["channels"],
@@ -555,12 +649,17 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
                          "hbm_gbs": achieved_gbs, "valu_tflops": achieved_tflops,
                          "kernel_flops_per_sample": wl["flops_per_sample"],
                          "kernel_ms": kern_ms_avg, "kernel_ms_min": float(np.min(kern_ms)),
+                         "kernel_ms_per_rank": per_rank_ms,
                          "algorithmic_bytes_per_launch": wl["step_bytes"]},
         }
-        if with_gather is not None:
-            out["value_with_gather"] = units_all / with_gather[0] / 1e6
-            out["gather"] = {"ms_per_step_with_gather": with_gather[0] * 1e3, "steps": with_gather[1],
-                             "what": "every rank's output slice gathered on rank 0 after each step (torch.distributed gather)"}
+        if with_gather:
+            best = min(with_gather, key=lambda k: with_gather[k][0])
+            out["value_with_gather"] = units_all / with_gather[best][0] / 1e6
+            out["gather"] = {"transport": best, "steps": with_gather[best][1],
+                             "ms_per_step_with_gather": {k: v[0] * 1e3 for k, v in with_gather.items()},
+                             "what": "every rank's output slice collected in one preallocated buffer on rank 0 after each step "
+                                     "(sharding.GatherPlan: sizes from the plan, no allocation per step); p2p = every rank sends "
+                                     "straight into its place (batch_isend_irecv), gather = the rooted collective"}
         tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if args.pmc and world == 1:
             live = collect_traffic(args.workload, args.path)
@@ -572,9 +671,10 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
             with open(tj) as f:
                 rec = json.load(f)
             out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = "profiles/traffic_%s.json: %s" % (
-                args.workload, rec.get("source", "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE passes of this command"))
-        if not args.no_cpu_baseline and world == 1 and wl.get("cpu_spec") is not None:
+            out["roofline"]["traffic_source"] = "profiles/traffic_%s.json (%s; NOT measured in this run, pass --pmc for that): %s" % (
+                args.workload, traffic_file_version(tj), rec.get("source", "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE passes of this command"))
+        if not args.no_cpu_baseline and wl.get("cpu_spec") is not None:
+            # rank 0's host cores, after the timed region (the other ranks wait at the end of the run)
             out["cpu_baseline"] = cpu_baseline(wl["cpu_spec"])
         else:
             out["cpu_baseline"] = None

@@ -123,7 +123,16 @@ uint64_t move_payload(int in_fd, int out_fd, uint64_t n, const FdKind& in, const
             }
         }
         if (r < 0) {
-            if (errno == EPIPE || errno == EIO || errno == ENOSPC) *ok = false;
+            if (errno == EAGAIN || errno == EWOULDBLOCK) {
+                // a non-blocking descriptor with nothing to take or no room: wait for either end, like the buffered
+                // path's blocking read / write would, and go again
+                struct pollfd p[2] = {{in_fd, POLLIN, 0}, {out_fd, POLLOUT, 0}};
+                (void)::poll(p, 2, 100);
+                continue;
+            }
+            // any other failure no fallback above has absorbed is an error of the move, never a quiet end of
+            // the stream in mid-packet
+            *ok = false;
             break;
         }
         if (r == 0) break; // end of input inside the payload

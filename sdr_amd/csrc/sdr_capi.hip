@@ -92,6 +92,14 @@ struct sdr_fir {
     // stream, so graph replays of a captured call and direct calls continue one another.
     float* d_hist[2] = {nullptr, nullptr};
     FirDevState* d_state = nullptr;
+    // Onset of the stream.  kfr::fir is a direct form: each output is rounded relative to itself.  The overlap-save
+    // kernels round at the level of the whole filter's spectrum, which a stream still SHORTER than the filter has
+    // not reached (a windowed design's first taps are tiny: its onset lies orders of magnitude below the settled
+    // level).  Calls that end inside the first ntaps samples of a stream therefore run the direct form (same
+    // history buffers, same device state), when its staging fits the LDS (up to ~14k taps).  Host-side count,
+    // saturating at ntaps; a captured call counts as past the onset (nobody knows how often it will be replayed).
+    size_t onset_seen = 0;
+    bool onset_direct = false;
     // Host-buffer entry points: one stream per staging slot, so that the device-to-host copy of
     // batch k (slot s) overlaps the host-to-device copy of batch k+1 (slot s^1) -- PCIe is full
     // duplex.  The filter kernels still run in submission order: each waits for the event recorded
@@ -250,7 +258,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if (use_fft) {
         f->fft_halo = fft_halo;
         f->fft_parts = fft_parts;
-        f->hist_len = (fft_parts > 1 ? fft_parts * 2048 : fft_halo) + 4;
+        f->hist_len = std::max((fft_parts > 1 ? fft_parts * 2048 : fft_halo) + 4, plan.hist_len); // (both even)
         if (sample_kind == SDR_REAL && stride == 2 && shift == 0 && plan.kept >= 2) {
             fir_fft_plan(plan.kept, &f->pair_halo, &f->pair_parts);
             f->fft_pair = true;
@@ -271,6 +279,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if (guard.err != hipSuccess) return bail(guard.err, "hipSetDevice");
     if (!use_fft && (e = prepare_kernel(*k, nchunks)) != hipSuccess)
         return bail(e, "tap count too large for the direct-form kernel");
+    if (use_fft) f->onset_direct = prepare_kernel(*k, nchunks) == hipSuccess; // the direct form takes the stream's onset
     const size_t hist_bytes = channels * (size_t)f->hist_len * f->w * sizeof(float);
     if ((e = hipMalloc(&f->d_taps, g.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(taps)");
     if ((e = hipMalloc(&f->d_hist[0], hist_bytes)) != hipSuccess) return bail(e, "hipMalloc(history)");
@@ -446,7 +455,13 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
         const uintptr_t o1 = o0 + ((f->channels - 1) * out_stride + n) * wbytes;
         if (i0 < o1 && o0 < i1) return fail(SDR_ERR_INVALID, "sdr_fir_process_device: in and out overlap");
     }
-    if (f->use_fft) {
+    bool onset_call = false;
+    if (f->use_fft && f->onset_seen < f->ntaps) {
+        if (stream_is_capturing(stream)) f->onset_seen = f->ntaps;
+        else if (f->onset_direct && f->onset_seen + n <= f->ntaps) onset_call = true;
+        f->onset_seen = std::min(f->ntaps, f->onset_seen + n);
+    }
+    if (f->use_fft && !onset_call) {
         FftArgs fa = {};
         fa.in = d_in;
         fa.out = d_out;
@@ -606,6 +621,7 @@ extern "C" int sdr_fir_reset(sdr_fir_t* f) {
     SDR_HIP(hipStreamSynchronize(f->stream));
     SDR_HIP(hipStreamSynchronize(f->stream1));
     f->have_filtered = false;
+    f->onset_seen = 0;
     const size_t hist_bytes = f->channels * (size_t)f->hist_len * f->w * sizeof(float);
     SDR_HIP(hipMemsetAsync(f->d_hist[0], 0, hist_bytes, f->stream));
     SDR_HIP(hipMemsetAsync(f->d_hist[1], 0, hist_bytes, f->stream));
@@ -1044,6 +1060,7 @@ int sdr_amd::fir_process_generated(sdr_fir_t* f, sdr_gen_t* g, size_t blocks, fl
     fa.gen.waveform = g->waveform;
     fa.gen.enabled = 1;
     fft_common_args(f, fa);
+    f->onset_seen = std::min(f->ntaps, f->onset_seen + (size_t)fa.n);
     SDR_HIP(launch_fir_fft(fa, true, f->fft_grid, stream));
     if (t) SDR_HIP(hipEventRecord(t->free, stream));
     else return gen_mark_launch(g, stream);

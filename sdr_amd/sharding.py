@@ -80,10 +80,82 @@ def plan_generated_chain(n_blocks, world, block_size, chain_ntaps, min_seek=None
     return plan
 
 
+class GatherPlan:
+    """Result collection for a sharded call: every rank's output slice into ONE buffer on rank `dst`, laid out
+    in rank order.  Built once from the sharding plan -- every rank knows every slice length, so nothing is
+    exchanged or synchronised to learn sizes -- and reused for every step: the destination buffer is allocated
+    here, once (empty, not zero-filled: every element is written by the gather), and a step allocates nothing.
+
+    counts: elements of the leading dimension each rank contributes (the plan: plan_chunks / plan_channels);
+    tail: shape of one element (e.g. (n,) for a channel of n samples, (n, 2) complex); dtype / device: of the
+    slices on this rank.  On ranks other than dst no buffer is held.
+
+    Two transports, same result:
+      "p2p"    -- every rank sends its slice straight into its place in rank dst's buffer (one batch of
+                  point-to-point operations; RCCL moves each over the sender's own xGMI link, so the 7 links
+                  into dst work at once).  Ragged slices need no padding.
+      "gather" -- the rooted collective (torch.distributed.gather; ring / tree inside RCCL).  Equal slices only.
+    Compute never waits on this: it is result collection."""
+
+    def __init__(self, counts, tail, dtype, device, dist, dst=0):
+        import torch
+        self.dist, self.dst = dist, dst
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        if len(counts) != self.world:
+            raise ValueError("one count per rank")
+        self.counts = [int(c) for c in counts]
+        self.tail = tuple(tail)
+        self.offsets = [0]
+        for c in self.counts:
+            self.offsets.append(self.offsets[-1] + c)
+        self.equal = len(set(self.counts)) == 1
+        self.host = dist.get_backend() != "nccl"   # the CPU rehearsal backend (gloo) moves host tensors
+        dev = "cpu" if self.host else device
+        self.out = None
+        self.views = None
+        if self.rank == dst:
+            self.out = torch.empty((self.offsets[-1],) + self.tail, dtype=dtype, device=dev)
+            self.views = [self.out[self.offsets[r]:self.offsets[r + 1]] for r in range(self.world)]
+        # the rehearsal backend needs a host copy of this rank's slice: one staging buffer, allocated once
+        self.stage = torch.empty((self.counts[self.rank],) + self.tail, dtype=dtype, device="cpu") if self.host else None
+
+    def _mine(self, y):
+        if tuple(y.shape) != (self.counts[self.rank],) + self.tail:
+            raise ValueError("slice shape %s does not match the plan %s" % (tuple(y.shape), (self.counts[self.rank],) + self.tail))
+        if self.host and y.is_cuda:
+            self.stage.copy_(y)
+            return self.stage
+        return y
+
+    def run(self, y, transport="p2p"):
+        """Collect this step's slices; returns the whole buffer on dst (rank order), None elsewhere."""
+        y = self._mine(y)
+        dist = self.dist
+        if transport == "gather":
+            if not self.equal:
+                raise ValueError("the rooted gather needs equal slices; use transport='p2p'")
+            dist.gather(y, self.views if self.rank == self.dst else None, dst=self.dst)
+        elif transport == "p2p":
+            ops = []
+            if self.rank == self.dst:
+                self.views[self.dst].copy_(y)
+                ops = [dist.P2POp(dist.irecv, self.views[r], r) for r in range(self.world)
+                       if r != self.dst and self.counts[r]]
+            elif self.counts[self.rank]:
+                ops = [dist.P2POp(dist.isend, y, self.dst)]
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        else:
+            raise ValueError("transport must be 'p2p' or 'gather'")
+        return self.out
+
+
 def gather_chunks(y, dist, dst=0):
-    """Gather every rank's output slice on rank `dst` (torch.distributed, any
-    backend; slices may differ in length).  Returns the list of slices on dst, None
-    elsewhere.  Compute never waits on this: it is result collection only."""
+    """One-off convenience form for callers that do NOT know the plan (sizes are exchanged, buffers are
+    allocated per call): gather every rank's output slice on rank `dst` (torch.distributed, any backend;
+    slices may differ in length).  Returns the list of slices on dst, None elsewhere.  Anything that repeats
+    -- bench.py, a serving loop -- uses GatherPlan, which allocates once and exchanges nothing."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     if y.is_cuda and dist.get_backend() != "nccl":

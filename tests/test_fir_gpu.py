@@ -434,6 +434,32 @@ def test_hip_graph_of_two_calls_replays_as_a_stream(kind, ntaps, cplx):
     assert rel_err(np.concatenate(got), O.fir(taps, x)) <= TOL
 
 
+@pytest.mark.parametrize("ntaps,cplx,cuts", [(4604, False, [396]), (4604, True, [100, 200, 396, 4000, 4604, 4700, 30000]),
+                                             (2500, False, [1, 2499, 2500, 2501, 9000]), (1000, True, [999, 5000]),
+                                             (127, False, [50, 126, 127, 4000])])
+def test_onset_of_a_stream_shorter_than_its_filter(ntaps, cplx, cuts):
+    """kfr::fir rounds every output relative to itself (libs/kfr/dsp/fir.hpp:137-143).  A stream still shorter than
+    its filter is all onset: with a windowed design the first taps are tiny and the output lies orders of magnitude
+    below the settled level -- below the rounding of a fast convolution, which works at the level of the whole
+    spectrum.  Calls that end inside the first ntaps samples run the direct form; every PIECE of the stream is held
+    to 1e-5 of ITS OWN output's RMS here (the first case is seed 307 of the round-2 fuzz soak: 4604 taps, 396
+    samples), and a reset starts the onset again."""
+    rng = np.random.default_rng(ntaps + cplx)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+    n = cuts[-1]
+    x = rand(rng, n, cplx)
+    st = sdr_amd.FirState(taps, cplx)
+    assert "fft" in st.kernel_name
+    want = O.fir(taps, x)
+    for rep in range(2):
+        lo = 0
+        for hi in cuts:
+            y = sdr_amd.fir(st, x[lo:hi])
+            assert rel_err(y, want[lo:hi]) <= TOL, (rep, lo, hi)
+            lo = hi
+        st.reset()
+
+
 def test_in_place_is_refused():
     """Tiles re-read their neighbours' inputs: the ABI says in and out must not overlap, and
     the library checks rather than filter its own outputs."""

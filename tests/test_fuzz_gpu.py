@@ -1,11 +1,11 @@
 """Seeded differential fuzz of the streaming FIR through the C ABI against the oracle:
 random tap counts (both kernel families and every halo / partition class), real and complex
 samples, 1..4 channels with padded strides, streams cut at random points (tile-sized, tiny and
-empty calls).  Bar: 1e-5 of the expected output's RMS, as everywhere -- except for a stream far shorter than
-its filter, whose whole output is the onset of the response and lies orders of magnitude below the level the
-filter settles at: the overlap-save kernels round at the level of the FULL filter's spectrum, so there the bar is
-1e-5 of a twentieth of the settled level (|taps|_2 x input RMS), i.e. 5e-7 of full scale (seed 307 of a
-400-seed run: 4604 taps, 396 samples, output RMS 0.13 where the settled level is 19.6, error 1.9e-6 absolute)."""
+empty calls).  Bar: 1e-5 of the expected output's RMS, as everywhere -- no exception.  (Round 2 needed one for
+a stream far shorter than its filter -- seed 307 of a 400-seed run: 4604 taps on 396 samples, an output that is all
+onset, orders of magnitude below the level the filter settles at, where the overlap-save kernels round at the level
+of the FULL filter's spectrum.  Calls that end inside the first ntaps samples of a stream now run the direct form,
+like kfr::fir itself: tests/test_fir_gpu.py::test_onset_of_a_stream_shorter_than_its_filter.)"""
 import os
 
 import numpy as np
@@ -70,7 +70,6 @@ def test_random_streams(seed):
         xc = x[c].reshape(-1).view(np.complex64) if cplx else x[c].reshape(-1)
         gc = got[c].reshape(-1).view(np.complex64) if cplx else got[c].reshape(-1)
         ref = O.fir(taps, xc)
-        settled = float(np.linalg.norm(taps.astype(np.float64)) * np.sqrt(np.mean(np.abs(xc.astype(np.complex128)) ** 2)))
         rms = float(np.sqrt(np.mean(np.abs(ref.astype(np.complex128)) ** 2)))
         err = float(np.max(np.abs(gc.astype(np.complex128) - ref.astype(np.complex128))))
-        assert err <= TOL * max(rms, 0.05 * settled), (seed, ntaps, cplx, C, n, bounds, st.kernel_name, c, err / rms)
+        assert err <= TOL * rms, (seed, ntaps, cplx, C, n, bounds, st.kernel_name, c, err / rms)

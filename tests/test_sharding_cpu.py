@@ -71,3 +71,58 @@ def test_chunked_stream_equals_whole_stream_gloo(world, cplx):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _gather_worker(rank, world, port, counts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tail = (5, 2)
+    plan = sharding.GatherPlan(counts, tail, torch.float32, "cpu", dist, dst=0)
+    out_ptr = plan.out.data_ptr() if rank == 0 else None
+    ok = True
+    transports = ["p2p", "gather"] if len(set(counts)) == 1 else ["p2p"]
+    for step in range(3):
+        for tr in transports:
+            # rank r's slice of step s: values that name (rank, step, position)
+            y = (torch.arange(counts[rank] * 10, dtype=torch.float32).reshape((counts[rank],) + tail)
+                 + 1000.0 * rank + 100000.0 * step)
+            got = plan.run(y, tr)
+            if rank == 0:
+                want = torch.cat([torch.arange(c * 10, dtype=torch.float32).reshape((c,) + tail) + 1000.0 * r + 100000.0 * step
+                                  for r, c in enumerate(counts)])
+                ok = ok and got.data_ptr() == out_ptr and bool(torch.equal(got, want))   # same buffer every step
+            else:
+                ok = ok and got is None
+    if len(set(counts)) != 1:
+        try:
+            plan.run(torch.zeros((counts[rank],) + tail), "gather")
+            ok = False
+        except ValueError:
+            pass
+    try:
+        plan.run(torch.zeros((counts[rank] + 1,) + tail), "p2p")
+        ok = False
+    except ValueError:
+        pass
+    q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [[8, 8], [22, 21, 21], [3, 0, 5]])
+def test_gather_plan_allocates_once_and_needs_no_size_exchange(counts):
+    """GatherPlan (what bench.py's value_with_gather times): sizes from the plan, one destination buffer reused
+    every step, both transports (direct point-to-point pushes into place; the rooted collective), ragged and
+    empty slices, shape mistakes refused."""
+    world = len(counts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + sum(counts)
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(q.get(timeout=5) for _ in range(world))
