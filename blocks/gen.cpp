@@ -84,7 +84,7 @@ private:
 FrequencyControl control;
 } // namespace
 
-int main(int argc, char* argv[]) {
+static int block_main(int argc, char* argv[]) {
     cli::Option freq = cli::Option::real("freq", "FREQ", 0.0f, true);
     cli::Option unit = cli::Option::choice("unit", kUnits, 0);
     cli::Option waveform = cli::Option::choice("waveform", kWaveforms, SDR_WAVE_COSINE);
@@ -245,6 +245,9 @@ int main(int argc, char* argv[]) {
     sdr_gen_destroy(g);
     sdr_host_free(bufs[0]);
     sdr_host_free(bufs[1]);
-    if (output_closed) host::die_of_sigpipe(); // the GPU is released; end like the reference does
+    if (output_closed) host::end_output_closed(); // the GPU is released; end like the reference does
     return rc;
 }
+
+// the body runs in a child process, so that a reader that goes away ends the block at once (host/wire.hpp)
+int main(int argc, char* argv[]) { return host::supervised_main(argc, argv, block_main); }

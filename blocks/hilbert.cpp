@@ -18,7 +18,7 @@
 #include "host/cli.hpp"
 #include "host/fir_pipeline.hpp"
 
-int main(int argc, char* argv[]) {
+static int block_main(int argc, char* argv[]) {
     cli::Option id = cli::Option::uint("stream", "ID", 0);
     cli::Option taps = cli::Option::uint("taps", "TAPS", 127);
     cli::Option delay = cli::Option::boolean("delay", true);
@@ -51,6 +51,9 @@ int main(int argc, char* argv[]) {
         host::FirPipeline pipe(cfg);
         rc = pipe.run(0, 1);
     } // (the GPU state is released here)
-    if (rc == host::FirPipeline::kOutputClosed) host::die_of_sigpipe(); // end like the reference: by SIGPIPE
+    if (rc == host::FirPipeline::kOutputClosed) host::end_output_closed(); // end like the reference: by SIGPIPE
     return rc;
 }
+
+// the body runs in a child process, so that a reader that goes away ends the block at once (host/wire.hpp)
+int main(int argc, char* argv[]) { return host::supervised_main(argc, argv, block_main); }

@@ -8,9 +8,13 @@
 #include <fcntl.h>
 #include <poll.h>
 #include <csignal>
+#include <cstdio>
+#include <cstdlib>
 #include <sys/sendfile.h>
 #include <sys/uio.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 namespace host {
@@ -245,10 +249,59 @@ bool route_packets(int in_fd, int out_fd, bool (*forwards)(const PacketHeader&, 
 
 void ignore_sigpipe() { (void)::signal(SIGPIPE, SIG_IGN); }
 
-void die_of_sigpipe() {
+namespace {
+constexpr int kOutputClosedStatus = 141; // child -> parent: "my reader went away" (what a shell shows for SIGPIPE)
+bool g_supervised = false;
+volatile sig_atomic_t g_child = 0;
+
+[[noreturn]] void die_of_sigpipe() {
     (void)::signal(SIGPIPE, SIG_DFL);
     (void)::raise(SIGPIPE);
-    ::_exit(141); // not reached unless SIGPIPE is blocked
+    ::_exit(kOutputClosedStatus); // not reached unless SIGPIPE is blocked
+}
+
+void pass_signal_on(int sig) {
+    if (g_child > 0) (void)::kill(static_cast<pid_t>(g_child), sig);
+}
+} // namespace
+
+void end_output_closed() {
+    std::fflush(nullptr);
+    if (g_supervised) std::exit(kOutputClosedStatus); // normal exit: the HIP runtime shuts itself down; the parent dies of SIGPIPE
+    die_of_sigpipe();
+}
+
+int supervised_main(int argc, char** argv, int (*body)(int, char**)) {
+    std::fflush(nullptr);
+    const pid_t parent = ::getpid();
+    const pid_t pid = ::fork();
+    if (pid < 0) return body(argc, argv);
+    if (pid == 0) {
+        (void)::prctl(PR_SET_PDEATHSIG, SIGKILL);
+        if (::getppid() != parent) ::_exit(1); // the parent is gone already
+        g_supervised = true;
+        const int rc = body(argc, argv);
+        std::fflush(nullptr);
+        std::exit(rc & 0xff);
+    }
+    g_child = pid;
+    for (int sig : {SIGTERM, SIGINT, SIGHUP, SIGQUIT}) (void)::signal(sig, pass_signal_on);
+    (void)::signal(SIGPIPE, SIG_IGN);
+    // the streams belong to the child: its reader sees the end of the stream, and its writer the closed pipe,
+    // the moment the CHILD goes
+    (void)::close(0);
+    (void)::close(1);
+    int status = 0;
+    while (::waitpid(pid, &status, 0) < 0) {
+        if (errno != EINTR) return 1;
+    }
+    if (WIFSIGNALED(status)) {
+        (void)::signal(WTERMSIG(status), SIG_DFL);
+        (void)::raise(WTERMSIG(status));
+        return 128 + WTERMSIG(status);
+    }
+    if (WEXITSTATUS(status) == kOutputClosedStatus) die_of_sigpipe();
+    return WEXITSTATUS(status);
 }
 
 PacketReader::PacketReader(int fd) : fd_(fd), buf_(1u << 20) { widen_pipe(fd); }

@@ -41,12 +41,20 @@ size_t read_full(int fd, void* dst, size_t size);
 bool write_full(int fd, const void* src, size_t size);
 // Best effort: a 1 MiB kernel buffer for a pipe end (no effect on other descriptors).
 void widen_pipe(int fd);
-// Blocks that hold GPU state: a closed output must not kill the process in the middle of GPU
-// work (tearing down a process with queues in flight costs the driver ~0.2 s).  SIGPIPE is
-// ignored while the block runs -- writes fail with EPIPE instead, the block releases the GPU --
-// and die_of_sigpipe() then ends the process the way the reference ends: killed by SIGPIPE.
+// Blocks that hold GPU state.  The reference's blocks die of SIGPIPE when their reader goes away.  A process
+// with a live HIP runtime that is KILLED -- or leaves through _exit -- lingers ~0.2 s while the driver tears
+// its queues down; only a normal exit(), which runs the runtime's own shutdown, ends at once (measured:
+// profiles/r03_c1pipe_startup.txt -- hipDeviceReset before the signal does not help).  So a GPU block runs its
+// body in a child process (supervised_main): SIGPIPE is ignored there, a write that fails with EPIPE makes the
+// body release its handles and leave through end_output_closed() -- a normal exit with a status of its own --
+// and the PARENT, which never touches the GPU and holds neither stdin nor stdout, then ends the way the
+// reference ends: killed by SIGPIPE.  `gen | head -c N` takes 65 ms instead of 255.
 void ignore_sigpipe();
-[[noreturn]] void die_of_sigpipe();
+[[noreturn]] void end_output_closed();
+// Runs body(argc, argv) in a child and hands its exit status (or its fatal signal) on; SIGTERM / SIGINT /
+// SIGHUP / SIGQUIT to the parent are passed to the child, and the child is killed if the parent dies.  Where
+// fork fails the body runs unsupervised.
+int supervised_main(int argc, char** argv, int (*body)(int, char**));
 // True when a read on fd would not block right now (data or EOF pending).
 bool input_ready(int fd);
 

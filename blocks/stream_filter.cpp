@@ -60,7 +60,7 @@ bool forward_cb(const host::PacketHeader& h, void* ctx) { return static_cast<Rul
 
 } // namespace
 
-int main(int argc, char* argv[]) {
+static int block_main(int argc, char* argv[]) {
     cli::Option mode = cli::Option::choice("mode", kModes, 0, /*required=*/true);
     cli::Option ids = cli::Option::uint_set("stream", "ID,...");
     cli::Option content = cli::Option::choice_set("content", kContents);
@@ -134,6 +134,9 @@ int main(int argc, char* argv[]) {
         host::FirPipeline pipe(cfg);
         rc = pipe.run(0, 1);
     } // (the GPU state is released here)
-    if (rc == host::FirPipeline::kOutputClosed) host::die_of_sigpipe(); // end like the reference: by SIGPIPE
+    if (rc == host::FirPipeline::kOutputClosed) host::end_output_closed(); // end like the reference: by SIGPIPE
     return rc;
 }
+
+// the body runs in a child process, so that a reader that goes away ends the block at once (host/wire.hpp)
+int main(int argc, char* argv[]) { return host::supervised_main(argc, argv, block_main); }

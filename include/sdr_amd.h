@@ -88,7 +88,14 @@ int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_
  * n outputs per channel; afterwards the history holds the last ntaps-1 inputs,
  * so results do not depend on how a stream is cut into calls.  Asynchronous on
  * `hip_stream` (a hipStream_t, NULL = the default stream); in and out must not
- * overlap.  Allocates nothing. */
+ * overlap.  Allocates nothing, synchronises nothing, and keeps no position of the
+ * stream on the host: which history buffer is current (and the kernels' tile
+ * counters) is device state that the kernels read and move on themselves, so a call
+ * recorded into a HIP graph replays as the stream's NEXT call, any number of times,
+ * and replays mix with ordinary calls (launches on one handle must be stream-ordered).
+ * While a stream is still shorter than its filter, calls run the direct form (each
+ * output rounded relative to itself, like kfr::fir); a captured call counts as past
+ * that onset. */
 int sdr_fir_process_device(sdr_fir_t* f, const void* d_in, size_t in_stride, size_t n,
                            void* d_out, size_t out_stride, void* hip_stream);
 
@@ -126,6 +133,8 @@ int sdr_fir_apply_device_noalloc(const float* taps, size_t ntaps, int sample_kin
 
 /* Replaces kfr::filter_fir::reset (reference libs/kfr/dsp/fir.hpp:195-199):
  * zero the history of every channel. */
+/* (Drains the handle's own streams; work the caller queued on a stream of their own is
+ * theirs to finish first, as before sdr_fir_destroy.) */
 int sdr_fir_reset(sdr_fir_t* f);
 void sdr_fir_destroy(sdr_fir_t* f);
 
@@ -154,7 +163,10 @@ int sdr_chain_create(sdr_chain_t** out, size_t nstages, const float* const* taps
 /* n input samples per channel in DEVICE memory -> *n_out output samples per channel
  * (n minus what the skips still swallow at the start of the stream), written from
  * d_out[c*out_stride].  Stream position, histories and pending skips carry from
- * call to call.  Asynchronous on hip_stream. */
+ * call to call.  Asynchronous on hip_stream.  Past the start of the stream (group-delay
+ * skips swallowed, staged warm-up done) a call is one call of the fused filter and may be
+ * recorded into a HIP graph like sdr_fir_process_device; inside that region a capture is
+ * refused (SDR_ERR_INVALID), because the work depends on the host-side position. */
 int sdr_chain_process_device(sdr_chain_t* c, const void* d_in, size_t in_stride, size_t n, void* d_out,
                              size_t out_stride, size_t* n_out, void* hip_stream);
 int sdr_chain_reset(sdr_chain_t* c);
@@ -208,7 +220,15 @@ int sdr_gen_advance(sdr_gen_t* g, size_t blocks);
 /* Replaces the body of the generator loop (blocks/gen.cpp:183-195, 224-229):
  * the next `blocks` packets' worth of samples, bit-for-bit the reference's fp32
  * recipe (polynomial sine, per-block phase recurrence), written to DEVICE
- * memory d_out, asynchronously on hip_stream. */
+ * memory d_out, asynchronously on hip_stream.  When the phase recurrence has a closed
+ * form -- phase and per-block increment whole multiples of 2^-23, e.g. 0.1 cycles per
+ * sample in 2044-sample packets from phase 0 or 45 degrees: no step of it ever rounds --
+ * the generator's position lives in device memory and the kernels move it on: no
+ * per-call phase table, and a call recorded into a HIP graph replays as the next
+ * packets.  Otherwise each call uploads the host's phase table and refuses capture
+ * (SDR_ERR_INVALID), as do the quadrature waveforms.  sdr_gen_set_frequency /
+ * sdr_gen_advance wait for the generating launches the library itself queued; finish
+ * graph replays before calling them. */
 int sdr_gen_generate_device(sdr_gen_t* g, size_t blocks, void* d_out, void* hip_stream);
 /* Same into HOST memory; returns when `out` is complete. */
 int sdr_gen_generate(sdr_gen_t* g, size_t blocks, void* out);
@@ -225,7 +245,9 @@ void sdr_gen_destroy(sdr_gen_t* g);
  * from d_out (DEVICE memory), asynchronously on hip_stream.  A chain short enough
  * for the direct-form kernel is moved to the overlap-save kernels (where the
  * generator lives) by its first call, which must then come before any
- * sdr_chain_process_device on that chain (or after sdr_chain_reset). */
+ * sdr_chain_process_device on that chain (or after sdr_chain_reset).  Past the start of
+ * the stream, with a closed-form generator (see sdr_gen_generate_device), one call
+ * recorded into a HIP graph replays as the stream's next call. */
 int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t blocks, void* d_out, size_t* n_out,
                               void* hip_stream);
 
@@ -233,6 +255,7 @@ int sdr_chain_generate_device(sdr_chain_t* c, sdr_gen_t* g, size_t blocks, void*
  * include/sdr/signal.hpp:41-69, for buffers that feed the GPU). */
 void* sdr_host_alloc(size_t bytes);
 void sdr_host_free(void* p);
+
 
 #ifdef __cplusplus
 }

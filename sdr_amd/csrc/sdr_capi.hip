@@ -655,6 +655,7 @@ extern "C" void sdr_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+
 // ---- generator -----------------------------------------------------------------
 
 struct sdr_gen {
