@@ -105,6 +105,11 @@ def kernel_flops_per_sample(kernel_name, ntaps, cplx, nonzero_taps, gen=False):
         return 2.0 * nonzero_taps * w            # one FMA per kept tap per real lane
     if "pairs" in kernel_name:                   # real samples filtered as complex pairs by the kept taps
         return kernel_flops_per_sample("fir_fft4096<COMPLEX>", nonzero_taps, True, nonzero_taps, gen) / 2.0
+    if "fft16k" in kernel_name:
+        # 16384-point tiles (fir_fft16k.hip): per lane and transform, three 16-point butterflies (176 flops), one
+        # stage of four 4-point ones (64) and 42 twiddle products (6 each): 844; 1024 lanes, two transforms and
+        # sixteen spectrum products per lane per tile of 16384 - halo outputs
+        return (2 * 844 * 1024 + 16 * 6 * 1024) / (16384.0 - (4096 if ntaps <= 4097 else 8192))
     halo = 64
     while halo + 1 < ntaps and halo < 2048:
         halo *= 2
@@ -446,7 +451,7 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=28)
     ap.add_argument("--chunk-log2", type=int, default=29, help="c5: samples per call")
     ap.add_argument("--unfused", action="store_true", help="c5: generator kernel + chain kernel through an HBM buffer")
-    ap.add_argument("--path", default="auto", choices=["auto", "direct", "fft", "mfma"],
+    ap.add_argument("--path", default="auto", choices=["auto", "direct", "fft", "mfma", "fft4k", "fft16k"],
                     help="experiments: pin the kernel family (the default is the library's own choice)")
     ap.add_argument("--pmc", action="store_true",
                     help="collect roofline.traffic live: two extra rocprofv3 --pmc passes of a short run (N=1 only)")

@@ -6,7 +6,7 @@ A=$1; B=$2; shift 2
 for round in 1 2 3; do
   for lib in $A $B; do
     for w in ${@:-c2 c1big}; do
-      SDR_AMD_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload $w --no-cpu-baseline --steps 60 --warmup 20 2>/dev/null | python3 -c "
+      SDR_AMD_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload $w ${BENCH_ARGS:-} --no-cpu-baseline --steps 60 --warmup 20 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -8,9 +8,12 @@ n = 1 << 26
 x = (torch.rand((n, 2), device="cuda") * 2 - 1).float()
 y = torch.empty_like(x)
 stream = torch.cuda.current_stream().cuda_stream
-for ntaps in (4095, 6143, 8191, 16383, 32767):
+PATHS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto"]
+for ntaps, path in [(t, p) for t in (2050, 4095, 6143, 8191, 8192, 16383, 32767) for p in PATHS]:
+    if path == "fft16k" and ntaps > 8192:
+        continue
     taps = S.fir_bandpass(ntaps, 0.05, 0.2)
-    f = S.FirState(taps, True, device=0) if hasattr(S, "FirState") else None
+    f = S.FirState(taps, True, device=0, path=path)
     for _ in range(5):
         f.process_device(x.data_ptr(), n, y.data_ptr(), stream=stream)
     torch.cuda.synchronize()
@@ -21,4 +24,4 @@ for ntaps in (4095, 6143, 8191, 16383, 32767):
         f.process_device(x.data_ptr(), n, y.data_ptr(), stream=stream)
     e1.record()
     torch.cuda.synchronize()
-    print("%6d taps (%2d partitions): %.3f ms per 2^26 complex samples" % (ntaps, (ntaps + 2047) // 2048, e0.elapsed_time(e1) / K), flush=True)
+    print("%6d taps (%2d partitions) %-8s %-24s %.3f ms per 2^26 complex samples" % (ntaps, (ntaps + 2047) // 2048, path, f.kernel_name, e0.elapsed_time(e1) / K), flush=True)

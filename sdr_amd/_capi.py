@@ -149,7 +149,7 @@ class FirState:
     `channels` independent streams.  History is zero after construction and is
     carried from call to call, like kfr::fir_state in the reference."""
 
-    PATHS = {"auto": -1, "direct": 0, "fft": 1, "mfma": 2}
+    PATHS = {"auto": -1, "direct": 0, "fft": 1, "mfma": 2, "fft4k": 3, "fft16k": 4}
 
     def __init__(self, taps, complex_samples=False, channels=1, device=0, path="auto", grid=0):
         """path / grid: tests and experiments only -- pin the kernel family ("direct", "fft" =

@@ -86,7 +86,18 @@ struct FftArgs {
     // (launches on one handle are stream-ordered).  NULL: tiles are grid-strided.
     unsigned* tickets;
     int resident;         // workgroups of the single-partition kernels resident on the device at once (0: unknown)
+    // 16384-point kernel (fir_fft16k.hip; complex samples, 2050..8193 taps): its spectrum (one, in that kernel's lane
+    // order) and twiddles; use16k: the interior of every channel runs on it in tiles of 16384 - halo16k outputs
+    // (launch_fir_fft sets big_first / big_tiles and leaves the 2048-sample tiles at both ends to the edge workgroups)
+    const float* hperm16k;
+    const float* wtab16k;
+    int use16k, halo16k, cus16k;
+    long long big_first, big_tiles;
 };
+constexpr size_t FFT16K_TWIDDLE_COMPLEX = 16384 + 1024 + 64;
+hipError_t launch_fir_fft16k_interior(const FftArgs& a, int grid_blocks, hipStream_t stream);
+void fir_fft16k_permute_spectrum(const float* h_natural, float* hperm); // 16384 complex
+void fir_fft16k_fill_twiddles(const double* cs, const double* sn, float* wtab);
 #ifndef SDR_FFT_TICKETS
 #define SDR_FFT_TICKETS 2 // measured 2 / 8 / 32: C2 0.789 / 0.795 / 0.808 ms (one counter serialises at ~12 ns per ticket: too slow)
 #endif
@@ -98,7 +109,8 @@ const char* fir_fft_kernel_name(bool real);
 void fir_fft_plan(size_t ntaps, int* halo, int* parts);
 
 // kernel families a handle can be pinned to (internal; the public create chooses by tap count)
-enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1, SDR_PATH_MFMA = 2 };
+// FFT4K: overlap-save with 4096-point tiles only (tests hold both tile sizes to parity where AUTO picks 16384)
+enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1, SDR_PATH_MFMA = 2, SDR_PATH_FFT4K = 3, SDR_PATH_FFT16K = 4 };
 
 // direct-form plan of a tap vector (sdr_capi.hip: plan_direct)
 struct DirectPlan {

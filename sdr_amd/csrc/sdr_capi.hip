@@ -85,6 +85,12 @@ struct sdr_fir {
     bool fft_pair = false;
     int pair_halo = 0, pair_parts = 1, pair_grid = 0, pair_resident = 0;
     float* d_hperm_pair = nullptr; // spectra of the kept taps
+    // 16384-point kernel (fir_fft16k.hip): complex samples, 2050..8193 taps
+    int use16k = 0; // 0 no, 1 by the size of the call, 2 always (asked for by name)
+    int halo16k = 0;
+    float* d_hperm16k = nullptr;   // its one spectrum, then its twiddles
+    const float* d_wtab16k = nullptr;
+    int cus = 256;
     unsigned* d_tickets = nullptr; // tile-ticket counters behind the twiddle table (FftArgs::tickets): zero between calls
     int fft_resident = 0;
     // The stream's history: the last hist_len samples, in one of two buffers; WHICH one is device state
@@ -181,6 +187,33 @@ void sdr_amd::plan_direct_fill(const float* taps, const DirectPlan& p, float* g)
     for (size_t i = 0; i < p.taps_floats; ++i) g[i] = i < p.kept ? taps[p.stride * i + p.shift] : 0.0f;
 }
 
+// whether sdr_fir_create picks the 16384-point tiles by itself for complex filters of 2050..8193 taps
+#ifndef SDR_FFT16K_AUTO
+#define SDR_FFT16K_AUTO 1
+#endif
+
+// in-place radix-2 FFT in double (forward, exp(-i ...)); n = re.size() a power of two; cs / sn = cos / sin(2 pi m / n)
+static void fft_radix2(std::vector<double>& re, std::vector<double>& im, const std::vector<double>& cs, const std::vector<double>& sn) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t step = n / len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = cs[k * step], wi = -sn[k * step];
+                const size_t a = i + k, b = i + k + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+
 // path: SDR_PATH_AUTO = choose by tap count (measured crossovers), or one kernel family forced
 // (internal callers and the test hook below; the public sdr_fir_create always passes AUTO).
 // grid: workgroups of the persistent overlap-save kernels (0 = the default for the device).
@@ -194,7 +227,8 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
         return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
     if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
-    if (path < SDR_PATH_AUTO || path > SDR_PATH_MFMA) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
+    if (path < SDR_PATH_AUTO || path > SDR_PATH_FFT16K) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
+    const bool want_fft = path == SDR_PATH_FFT || path == SDR_PATH_FFT4K || path == SDR_PATH_FFT16K;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -222,7 +256,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
 #ifdef SDR_AMD_DIAG
     if (const char* ev = getenv("SDR_AMD_FFT")) use_fft = atoi(ev) != 0 && fft_parts <= 64;
 #endif
-    if (path != SDR_PATH_AUTO) use_fft = path == SDR_PATH_FFT && fft_parts <= 64;
+    if (path != SDR_PATH_AUTO) use_fft = want_fft && fft_parts <= 64;
 
     sdr_fir* f = new (std::nothrow) sdr_fir();
     if (!f) return fail(SDR_ERR_NOMEM, "sdr_fir_create: out of memory");
@@ -361,6 +395,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         // them leave a shorter tail than two (same-box sweep: 9 per CU 1 % ahead of 6, 12 and 16 level)
         f->fft_grid = cus * env_int("SDR_AMD_FFT_BLOCKS_PER_CU", fft_parts > 1 ? 2 : 9);
         f->fft_resident = cus * (fft_parts > 1 ? 2 : 3);
+        f->cus = cus;
         f->pair_grid = grid > 0 ? grid : cus * (f->pair_parts > 1 ? 2 : 9);
         f->pair_resident = cus * (f->pair_parts > 1 ? 2 : 3);
         // tests: a tiny grid makes every workgroup walk long runs of tiles across channels
@@ -369,6 +404,31 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         f->fft_ablate = env_int("SDR_AMD_FFT_ABLATE", 0);
         f->fft_contig = env_int("SDR_AMD_FFT_CONTIG", 0);
 #endif
+    }
+    // 16384-point tiles: complex samples, more than one and at most four 2048-tap partitions (2050..8193 taps)
+    if (use_fft && sample_kind == SDR_COMPLEX && fft_parts >= 2 && fft_parts <= 4 && path != SDR_PATH_FFT4K &&
+        (path == SDR_PATH_FFT16K || SDR_FFT16K_AUTO)) {
+        const int NK = 16384;
+        std::vector<double> cs(NK), sn(NK), re(NK, 0.0), im(NK, 0.0);
+        for (int m = 0; m < NK; ++m) {
+            cs[m] = std::cos(2.0 * M_PI * m / NK);
+            sn[m] = std::sin(2.0 * M_PI * m / NK);
+        }
+        for (size_t j = 0; j < ntaps; ++j) re[j] = taps[j];
+        fft_radix2(re, im, cs, sn);
+        std::vector<float> nat((size_t)2 * NK), hk((size_t)2 * NK + 2 * FFT16K_TWIDDLE_COMPLEX);
+        for (int k = 0; k < NK; ++k) {
+            nat[2 * k] = (float)(re[k] / NK);
+            nat[2 * k + 1] = (float)(im[k] / NK);
+        }
+        fir_fft16k_permute_spectrum(nat.data(), hk.data());
+        fir_fft16k_fill_twiddles(cs.data(), sn.data(), hk.data() + (size_t)2 * NK);
+        if ((e = hipMalloc(&f->d_hperm16k, hk.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
+        if ((e = hipMemcpy(f->d_hperm16k, hk.data(), hk.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
+            return bail(e, "hipMemcpy(spectrum)");
+        f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK;
+        f->halo16k = ntaps - 1 <= 4096 ? 4096 : 8192;
+        f->use16k = path == SDR_PATH_FFT16K ? 2 : 1;
     }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
     if ((e = hipMemset(f->d_hist[1], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
@@ -415,6 +475,7 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (f->d_atab) (void)hipFree(f->d_atab);
     if (f->d_hperm) (void)hipFree(f->d_hperm);
     if (f->d_hperm_pair) (void)hipFree(f->d_hperm_pair);
+    if (f->d_hperm16k) (void)hipFree(f->d_hperm16k);
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
     if (f->d_state) (void)hipFree(f->d_state);
@@ -490,6 +551,13 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
             fa.halo = f->fft_halo;
             fa.hist_len = f->hist_len;
             fa.parts = f->fft_parts;
+            if (f->use16k) {
+                fa.use16k = f->use16k;
+                fa.halo16k = f->halo16k;
+                fa.hperm16k = f->d_hperm16k;
+                fa.wtab16k = f->d_wtab16k;
+                fa.cus16k = f->cus; // one 1024-lane workgroup per CU
+            }
             SDR_HIP(launch_fir_fft(fa, f->kind == SDR_REAL, f->fft_grid, stream));
         }
         return SDR_OK;
@@ -636,6 +704,7 @@ extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? (f->use_fft ?
 extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) {
     if (!f) return "";
     if (f->use_mfma) return fir_mfma_kernel_name(f->kind == SDR_REAL, f->k->stride);
+    if (f->use_fft && f->use16k) return f->use16k == 2 ? "fir_fft16k<COMPLEX>" : "fir_fft16k<COMPLEX> (short calls: fir_fft4096<COMPLEX>)";
     if (f->use_fft && f->fft_pair) return "fir_fft4096<REAL as complex pairs>";
     return f->use_fft ? fir_fft_kernel_name(f->kind == SDR_REAL) : f->k->name;
 }
