@@ -93,6 +93,11 @@
 #ifndef SDR_CACHE_H0_REGS
 #define SDR_CACHE_H0_REGS 1
 #endif
+// Fused-generator kernels: the sine behind the (bit-exact) phase argument with fused multiply-adds (1,
+// gen_device.h: gen_sine_pair_fast, 13 operations per sample) or in the reference's own operation order (0, 18).
+#ifndef SDR_GEN_FAST
+#define SDR_GEN_FAST 1
+#endif
 // Diagnostic builds (make diag): FftArgs::ablate can switch the arithmetic off to expose the
 // memory pattern.  The release library compiles the switch out.
 #ifdef SDR_AMD_DIAG
@@ -458,7 +463,8 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a0, f2* lds, LaneC
                 }
             }
             if constexpr (decltype(sine)::value) { // straight-line polynomial on both members at once
-                dst[n2] = gen_sine_pair(a.gen.amp, a.gen.cps, f2{s0.base, s1.base}, f2{s0.idx, s1.idx});
+                dst[n2] = SDR_GEN_FAST ? gen_sine_pair_fast(a.gen.amp, a.gen.cps, f2{s0.base, s1.base}, f2{s0.idx, s1.idx})
+                                       : gen_sine_pair(a.gen.amp, a.gen.cps, f2{s0.base, s1.base}, f2{s0.idx, s1.idx});
             } else {
                 dst[n2] = f2{gen_real_sample_f(a.gen.waveform, a.gen.amp, a.gen.cps, s0.p, s0.idx),
                              gen_real_sample_f(a.gen.waveform, a.gen.amp, a.gen.cps, s1.p, s1.idx)};

@@ -147,6 +147,39 @@ __device__ __forceinline__ gen_f2 gen_sine_pair(float amp, float cps, gen_f2 bas
     return r * -amp;
 }
 
+// The same two samples for the FIR kernels that synthesise their own input and hand it to an fp32 transform
+// (fir_fft.hip, GEN): cheaper, and NOT the same bits.  What has to be the reference's own rounding is the phase
+// argument base + cps * float(i): half an ulp of it is up to 1e-5 of a cycle, i.e. several times the parity bar,
+// so the product and the sum stay two correctly rounded operations.  Everything behind the fract is well
+// conditioned -- one rounding more or less moves the sample by ~1e-7 of the amplitude, below what the transform
+// that consumes it adds -- and is evaluated with fused multiply-adds: v_fract_f32 (equal to x - floor(x) except
+// where that rounds up to 1.0, where it returns the float below), the shift to [-pi, pi) as one fma, the odd
+// polynomial y + y^3 (c2 + c4 y^2 + c6 y^4) in Horner form, sign and amplitude folded into one factor.
+// 13 operations per sample where gen_sine_pair needs 18 (profiles/r03_gen_fast.txt).
+__device__ __forceinline__ gen_f2 gen_sine_pair_fast(float amp, float cps, gen_f2 base, gen_f2 idx) {
+    const float c2 = -0.16665853559970855712890625f;
+    const float c4 = +8.31427983939647674560546875e-3f;
+    const float c6 = -1.85423981747590005397796630859375e-4f;
+    const float pi = 3.14159265358979323846f;
+    const float two_pi = 6.28318530717958647692f;
+    gen_f2 arg;
+    {
+#pragma clang fp contract(off)
+        const gen_f2 step = idx * cps;
+        arg = base + step;
+    }
+    const gen_f2 fr = {__builtin_amdgcn_fractf(arg.x), __builtin_amdgcn_fractf(arg.y)};
+    const gen_f2 xx = __builtin_elementwise_fma(fr, gen_f2{two_pi, two_pi}, gen_f2{-pi, -pi});
+    const gen_f2 y = {fminf(fabsf(xx.x), pi - fabsf(xx.x)), fminf(fabsf(xx.y), pi - fabsf(xx.y))};
+    const gen_f2 y2 = y * y;
+    gen_f2 f = __builtin_elementwise_fma(y2, gen_f2{c6, c6}, gen_f2{c4, c4});
+    f = __builtin_elementwise_fma(f, y2, gen_f2{c2, c2});
+    const gen_f2 g = f * y2;
+    const gen_f2 ys = {__builtin_copysignf(y.x, xx.x), __builtin_copysignf(y.y, xx.y)};
+    const gen_f2 t = ys * -amp;
+    return __builtin_elementwise_fma(g, t, t);
+}
+
 // Start phase of block b of the call: exact integer arithmetic (every multiple of 2^-23 below 1 is a float, and
 // the scaling by a power of two is exact) or the host's table -- the same bits either way.
 __device__ __forceinline__ float gen_phase_closed(unsigned P0, unsigned pincr, unsigned b) {

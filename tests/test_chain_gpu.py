@@ -210,11 +210,17 @@ def test_generator_fused_into_the_fir_kernel(wf, amp, phase, rate, ntaps2, calls
         parts.append(o[:n_out].cpu().numpy())
     unfused = np.concatenate(parts)
     assert fused.shape == unfused.shape
-    assert rel_err(fused, unfused) <= 1e-6      # same samples, same tiles: only rounding-order noise at most
+    e_fu = rel_err(fused, unfused)
+    # same stream, same tiles; the fused kernels evaluate the sine behind the (bit-exact) phase argument with fused
+    # multiply-adds (gen_device.h: gen_sine_pair_fast), so samples differ by an ulp or two: measured 0.7-1.03e-6 of
+    # the output RMS here, with the distance to the oracle unchanged (0.65-1.0e-6 either way; bar TOL = 1e-5)
+    assert e_fu <= 2e-6, e_fu
 
     x, _ = O.gen_real(total, B, amp, cps, float(np.float32(phase) / np.float32(360.0)), sdr_amd.WAVEFORMS[wf])
     ref = staged_oracle(stages, x)
-    assert fused.shape == ref.shape and rel_err(fused, ref) <= TOL
+    e_ref = rel_err(fused, ref)
+    print("fused vs unfused %.3g, fused vs oracle %.3g, unfused vs oracle %.3g" % (e_fu, e_ref, rel_err(unfused, ref)))
+    assert fused.shape == ref.shape and e_ref <= TOL
 
 
 @pytest.mark.parametrize("B,nblocks", [(256, 300), (257, 200), (511, 150), (4096, 30), (5000, 20), (65536, 3), (1 << 20, 2)])
