@@ -7,7 +7,7 @@ for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         if any(k in name for k in ("fir_fft4096", "fir_fft16k", "fir_direct", "fir_mfma")):
-            short = re.sub(r"^void sdr_amd::", "", name.split("(")[0])
+            short = re.sub(r"^void sdr_amd::", "", name.replace("(anonymous namespace)::", "").split("(")[0])
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 # one table per kernel, the one with the most wave-cycles first; per-launch averages (first launch dropped)
 def avg(v):

@@ -26,7 +26,11 @@ __device__ __forceinline__ T stream_load(const T* p) {
 }
 template <class T>
 __device__ __forceinline__ void stream_store(T v, T* p) {
-#if SDR_ST_NT
+#if defined(SDR_ST_SCOPE)
+    // experiment: relaxed atomic stores carry the scope bits (workgroup sc0, agent sc1, system sc0 sc1), no nt
+    if constexpr (sizeof(T) == 8) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, SDR_ST_SCOPE);
+    else __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, SDR_ST_SCOPE);
+#elif SDR_ST_NT
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
