@@ -113,8 +113,15 @@ void FirPipeline::remember_tail(const Batch& b) {
 int FirPipeline::switch_kind(bool to_complex) {
     const int k = to_complex ? 1 : 0;
     if (!fir_[k]) {
-        if (sdr_fir_create(&fir_[k], cfg_.taps.data(), cfg_.taps.size(), to_complex ? SDR_COMPLEX : SDR_REAL, 1,
-                           cfg_.device) != SDR_OK)
+        // SDR_AMD_NUMERICS=per-output: the direct-form kernels whatever the tap count -- kfr::fir's own error
+        // character (each output rounded relative to itself, a NaN / Inf sample reaches ntaps outputs) at the
+        // direct form's cost; the default picks the quickest kernel family (include/sdr_amd.h)
+        const char* nm = std::getenv("SDR_AMD_NUMERICS");
+        const int numerics = (nm && std::strcmp(nm, "per-output") == 0) ? SDR_NUMERICS_PER_OUTPUT : SDR_NUMERICS_FAST;
+        if (nm && *nm && numerics == SDR_NUMERICS_FAST && std::strcmp(nm, "fast") != 0)
+            return report("SDR_AMD_NUMERICS must be fast or per-output");
+        if (sdr_fir_create_numerics(&fir_[k], cfg_.taps.data(), cfg_.taps.size(), to_complex ? SDR_COMPLEX : SDR_REAL, 1,
+                                    cfg_.device, numerics) != SDR_OK)
             return report("cannot create the GPU filter");
     }
     if (have_kind_ && cur_complex_ != to_complex) {

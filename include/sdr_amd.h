@@ -80,6 +80,24 @@ int sdr_fir_design_window(int kind, int window, float window_param, float* taps,
 int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
                    size_t channels, int device);
 
+/* The same constructor with the handle's NUMERICS chosen by the caller.  kfr::fir is a direct
+ * form (reference libs/kfr/dsp/fir.hpp:129-146: one dot product per output), so each output is
+ * rounded relative to itself and a NaN / Inf input sample reaches the next `ntaps` outputs and no
+ * other.  SDR_NUMERICS_FAST (what sdr_fir_create uses) picks the quickest kernel family per
+ * filter; from 33..88 taps up that is overlap-save, whose rounding error is relative to a 4096-
+ * or 16384-point tile (~3e-7 of the TILE's RMS: weak stretches next to strong ones see the strong
+ * ones' noise floor) and which loses the whole tile a non-finite sample sits in.
+ * SDR_NUMERICS_PER_OUTPUT keeps the handle on the direct-form kernels (VALU or fp32 matrix
+ * cores) whatever the tap count, with the reference's character: error relative to each output,
+ * non-finite samples confined to the ntaps outputs they reach (plus the kernels' zero padding,
+ * at most 144 neighbours) -- at the direct form's cost: hilbert's 127 taps 0.50 ms instead of
+ * 0.39 per 2^28 real samples, 127 dense taps 1.5 ms instead of 0.77 per 2^28 complex samples.
+ * Up to 14336 dense taps (the direct form's LDS window); longer filters are refused
+ * (SDR_ERR_INVALID).  The blocks take it from the environment: SDR_AMD_NUMERICS=per-output. */
+enum { SDR_NUMERICS_FAST = 0, SDR_NUMERICS_PER_OUTPUT = 1 };
+int sdr_fir_create_numerics(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                            size_t channels, int device, int numerics);
+
 /* Replaces `out = kfr::fir(state, in)` (reference libs/kfr/dsp/fir.hpp:167-171,
  * 119-148; call sites blocks/hilbert.cpp:72-73, blocks/gen.cpp:235) for buffers
  * ALREADY IN DEVICE MEMORY:  y[c][i] = sum_j h[j] x[c][i-j], i in [0,n), with
@@ -240,7 +258,9 @@ void sdr_gen_destroy(sdr_gen_t* g);
  * samples synthesised inside the FIR kernel -- no generated or intermediate stream is
  * written to memory (the few packets that overlap the start-of-stream warm-up are
  * materialised once, in a buffer the first call allocates).  Same results as
- * sdr_gen_generate_device followed by sdr_chain_process_device.  Real generator,
+ * sdr_gen_generate_device followed by sdr_chain_process_device within fp32 rounding (the
+ * fused kernels evaluate the sine behind the bit-exact phase argument with fused
+ * multiply-adds: samples an ulp or two from the packets' bits).  Real generator,
  * real one-channel chain, packets of 256..2^23 samples; *n_out outputs are written
  * from d_out (DEVICE memory), asynchronously on hip_stream.  A chain short enough
  * for the direct-form kernel is moved to the overlap-save kernels (where the

@@ -39,6 +39,7 @@ def lib():
         L.sdr_fir_design.argtypes = [C.c_int, fp, sz, C.c_float, C.c_float]
         L.sdr_fir_design_window.argtypes = [C.c_int, C.c_int, C.c_float, fp, sz, C.c_float, C.c_float]
         L.sdr_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int]
+        L.sdr_fir_create_numerics.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int, C.c_int]
         # test hook outside the C ABI (sdr_amd/csrc/internal.h): pins the kernel family
         L.sdr_amd_internal_fir_create.argtypes = [C.POINTER(vp), fp, sz, C.c_int, sz, C.c_int, C.c_int, C.c_int]
         L.sdr_fir_process_device.argtypes = [vp, vp, sz, sz, vp, sz, vp]
@@ -150,8 +151,9 @@ class FirState:
     carried from call to call, like kfr::fir_state in the reference."""
 
     PATHS = {"auto": -1, "direct": 0, "fft": 1, "mfma": 2, "fft4k": 3, "fft16k": 4}
+    NUMERICS = {"fast": 0, "per-output": 1}
 
-    def __init__(self, taps, complex_samples=False, channels=1, device=0, path="auto", grid=0):
+    def __init__(self, taps, complex_samples=False, channels=1, device=0, path="auto", grid=0, numerics=None):
         """path / grid: tests and experiments only -- pin the kernel family ("direct", "fft" =
         overlap-save) and the persistent grid
         through the library's internal hook; the default goes through sdr_fir_create."""
@@ -161,7 +163,10 @@ class FirState:
         self.device = int(device)
         self._h = C.c_void_p()
         kind = SDR_COMPLEX if self.complex_samples else SDR_REAL
-        if path == "auto" and not grid:
+        if numerics is not None:   # the public switch (sdr_fir_create_numerics): "fast" or "per-output"
+            _check(lib().sdr_fir_create_numerics(C.byref(self._h), _fp(taps), len(taps), kind, self.channels, self.device,
+                                                 self.NUMERICS[numerics] if isinstance(numerics, str) else int(numerics)))
+        elif path == "auto" and not grid:
             _check(lib().sdr_fir_create(C.byref(self._h), _fp(taps), len(taps), kind, self.channels, self.device))
         else:
             _check(lib().sdr_amd_internal_fir_create(C.byref(self._h), _fp(taps), len(taps), kind, self.channels,

@@ -110,7 +110,9 @@ void fir_fft_plan(size_t ntaps, int* halo, int* parts);
 
 // kernel families a handle can be pinned to (internal; the public create chooses by tap count)
 // FFT4K: overlap-save with 4096-point tiles only (tests hold both tile sizes to parity where AUTO picks 16384)
-enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1, SDR_PATH_MFMA = 2, SDR_PATH_FFT4K = 3, SDR_PATH_FFT16K = 4 };
+// DIRECT_FORMS: the public SDR_NUMERICS_PER_OUTPUT -- no overlap-save; matrix-core kernel where AUTO would pick it
+enum { SDR_PATH_AUTO = -1, SDR_PATH_DIRECT = 0, SDR_PATH_FFT = 1, SDR_PATH_MFMA = 2, SDR_PATH_FFT4K = 3, SDR_PATH_FFT16K = 4,
+       SDR_PATH_DIRECT_FORMS = 5 };
 
 // direct-form plan of a tap vector (sdr_capi.hip: plan_direct)
 struct DirectPlan {

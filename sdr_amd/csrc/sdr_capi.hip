@@ -227,7 +227,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     if (sample_kind != SDR_REAL && sample_kind != SDR_COMPLEX)
         return fail(SDR_ERR_INVALID, "sdr_fir_create: sample_kind must be SDR_REAL or SDR_COMPLEX");
     if (channels == 0 || channels > 65535) return fail(SDR_ERR_INVALID, "sdr_fir_create: channels must be 1..65535");
-    if (path < SDR_PATH_AUTO || path > SDR_PATH_FFT16K) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
+    if (path < SDR_PATH_AUTO || path > SDR_PATH_DIRECT_FORMS) return fail(SDR_ERR_INVALID, "sdr_fir_create: unknown kernel family");
     const bool want_fft = path == SDR_PATH_FFT || path == SDR_PATH_FFT4K || path == SDR_PATH_FFT16K;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -277,7 +277,7 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // 5.4-6.0 TB/s (0.67-0.75 of HBM peak) where the direct form has turned VALU-bound and the
     // overlap-save kernel sits at 5.1-5.3; below, the direct form is level or ahead; from 50 kept
     // taps up the fp32 matrix pipe is the bottleneck and the overlap-save kernel is faster.
-    const bool mfma_auto = path == SDR_PATH_AUTO && mfma_smax != 0 && plan.kept >= 17 && plan.kept <= 49;
+    const bool mfma_auto = (path == SDR_PATH_AUTO || path == SDR_PATH_DIRECT_FORMS) && mfma_smax != 0 && plan.kept >= 17 && plan.kept <= 49;
     if (mfma_auto) f->use_fft = use_fft = false;
     const bool use_mfma = mfma_auto || (!use_fft && path == SDR_PATH_MFMA);
     if (use_mfma && mfma_smax == 0) {
@@ -444,6 +444,17 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
 extern "C" int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
                               size_t channels, int device) {
     return fir_create_impl(out, taps, ntaps, sample_kind, channels, device, SDR_PATH_AUTO, 0);
+}
+
+extern "C" int sdr_fir_create_numerics(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_kind,
+                                       size_t channels, int device, int numerics) {
+    if (numerics != SDR_NUMERICS_FAST && numerics != SDR_NUMERICS_PER_OUTPUT) {
+        clear_error();
+        if (out) *out = nullptr;
+        return fail(SDR_ERR_INVALID, "sdr_fir_create_numerics: numerics must be SDR_NUMERICS_FAST or SDR_NUMERICS_PER_OUTPUT");
+    }
+    return fir_create_impl(out, taps, ntaps, sample_kind, channels, device,
+                           numerics == SDR_NUMERICS_PER_OUTPUT ? SDR_PATH_DIRECT_FORMS : SDR_PATH_AUTO, 0);
 }
 
 // Test hook (declared in csrc/internal.h, not part of include/sdr_amd.h): sdr_fir_create with the

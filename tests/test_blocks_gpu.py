@@ -54,6 +54,20 @@ def test_hilbert_block_matches_reference_stream(golden_dir, name, batch):
     assert rel_err(samples(got), samples(ref)) <= TOL
 
 
+@pytest.mark.parametrize("name", ["real_127", "complex_127", "real_4095_swallow"])
+def test_hilbert_block_per_output_numerics(golden_dir, name):
+    """SDR_AMD_NUMERICS=per-output keeps the block on the direct-form kernels (kfr::fir's own error
+    character, include/sdr_amd.h: sdr_fir_create_numerics): the same stream as the reference's."""
+    g = np.load(os.path.join(golden_dir, "hilbert.npz"))
+    out = run_block("hilbert", HILBERT_CASES[name], bytes(g[name + "_in"]), {"SDR_AMD_NUMERICS": "per-output"})
+    got, ref = O.parse_packets(out), O.parse_packets(bytes(g[name + "_out"]))
+    assert [p[:4] for p in got] == [p[:4] for p in ref]
+    assert rel_err(samples(got), samples(ref)) <= TOL
+    e = dict(os.environ, SDR_AMD_NUMERICS="exact")
+    p = subprocess.run([os.path.join(BIN, "hilbert")], input=bytes(g[name + "_in"]), capture_output=True, env=e, timeout=120)
+    assert p.returncode != 0 and b"SDR_AMD_NUMERICS must be fast or per-output" in p.stderr
+
+
 def test_hilbert_block_foreign_packets_once(golden_dir):
     """Interleaving kept, foreign packets forwarded byte-exact and ONCE (the
     reference's fall-through emits a garbage twin after each: SURVEY.md 8b Q1)."""

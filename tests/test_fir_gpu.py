@@ -435,6 +435,48 @@ def test_non_finite_sample_stays_local(path, ntaps, reach, bad):
     assert rel_err(y[keep], want[keep]) <= TOL
 
 
+@pytest.mark.parametrize("kind,ntaps,cplx,family", [("hilbert", 127, False, "fir_direct"), ("lowpass", 127, True, "fir_direct"),
+                                                    ("lowpass", 31, True, "fir_mfma"), ("bandpass", 4095, True, "fir_direct")])
+def test_per_output_numerics(kind, ntaps, cplx, family):
+    """sdr_fir_create_numerics(SDR_NUMERICS_PER_OUTPUT): the public switch that keeps a handle on the direct-form
+    kernels whatever the tap count, with kfr::fir's own character (libs/kfr/dsp/fir.hpp:129-146): parity as ever, a
+    NaN confined to the outputs it reaches, and -- what the overlap-save default cannot give -- a weak stretch of
+    the stream right behind a strong one held to the bar relative to ITS OWN level."""
+    rng = np.random.default_rng(ntaps)
+    taps = taps_for(kind, ntaps)
+    st = sdr_amd.FirState(taps, cplx, numerics="per-output")
+    assert family in st.kernel_name and "fft" not in st.kernel_name
+    fast = sdr_amd.FirState(taps, cplx, numerics="fast")
+    assert fast.kernel_name == sdr_amd.FirState(taps, cplx).kernel_name
+    n, cut = 60000, 30000
+    x = rand(rng, n, cplx)
+    x[:cut] *= 1e3
+    x[cut:] *= 1e-3
+    y = np.concatenate([sdr_amd.fir(st, x[:12345]), sdr_amd.fir(st, x[12345:])])
+    want = O.fir(taps, x)
+    assert rel_err(y, want) <= TOL
+    weak = slice(cut + ntaps, n)                       # past the filter's memory of the strong stretch
+    assert rel_err(y[weak], want[weak]) <= TOL         # relative to the weak stretch's own RMS (1e-6 of the strong one's)
+    if "fft" in fast.kernel_name:                      # the default path cannot: its error is relative to the tile
+        yf = sdr_amd.fir(fast, x)
+        assert rel_err(yf, want) <= TOL and rel_err(yf[weak], want[weak]) > TOL
+    st.reset()
+    x2 = rand(rng, n, cplx)
+    x2[cut] = np.nan
+    y2 = sdr_amd.fir(st, x2)
+    # (the every-other-tap kernel never multiplies the Hilbert design's zero taps: kfr::fir's NaN * 0 stays finite here)
+    assert not np.isfinite(y2[cut + np.flatnonzero(taps)]).any()
+    assert np.isfinite(y2[:cut - 144]).all() and np.isfinite(y2[cut + ntaps + 144:]).all()
+
+
+def test_per_output_numerics_arguments():
+    taps = taps_for("lowpass", 127)
+    with pytest.raises(sdr_amd.SdrError, match="numerics must be"):
+        sdr_amd.FirState(taps, True, numerics=7)
+    with pytest.raises(sdr_amd.SdrError, match="too large for the direct-form"):
+        sdr_amd.FirState(taps_for("lowpass", 20001), True, numerics="per-output")
+
+
 @pytest.mark.parametrize("kind,ntaps,cplx", [("lowpass", 127, True), ("hilbert", 127, False), ("lowpass", 31, True),
                                              ("lowpass", 15, False), ("bandpass", 4095, True)])
 def test_hip_graph_of_two_calls_replays_as_a_stream(kind, ntaps, cplx):
