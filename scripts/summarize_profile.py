@@ -30,7 +30,7 @@ for f in find("trace/**/*kernel_stats.csv"):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             if "fir_" in row["Name"] and "carry" not in row["Name"] and float(row["TotalDurationNs"]) > best:
-                best, dominant = float(row["TotalDurationNs"]), row["Name"].split("(")[0]
+                best, dominant = float(row["TotalDurationNs"]), row["Name"].replace("(anonymous namespace)::", "").split("(")[0]
 print("== dominant kernel:", dominant)
 res = {}
 for key, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
@@ -38,7 +38,7 @@ for key, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE
     for f in find(pat):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if dominant in row.get("Kernel_Name", "") and row.get("Counter_Name") == key:
+                if dominant in row.get("Kernel_Name", "").replace("(anonymous namespace)::", "") and row.get("Counter_Name") == key:
                     vals.append(float(row["Counter_Value"]))
     if vals:
         vals = vals[1:] or vals  # drop the warm-up launch

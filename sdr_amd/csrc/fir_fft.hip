@@ -917,7 +917,9 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     // 16384-point tiles for the interior (complex samples, two to four partitions' worth of taps): boundaries on
     // multiples of 2048, so that the 4096-point partitioned form takes the few tiles left at both ends as edge tiles
     a.big_tiles = 0;
-    if (a.use16k && !real && !a.gen.enabled && a.parts >= 2 && a.parts <= 4 && a.hperm16k && a.halo16k >= 2048 * a.parts) {
+    if (a.use16k && !a.gen.enabled && a.parts >= 2 && a.parts <= 4 && a.hperm16k && a.halo16k >= 2048 * a.parts) {
+        // (real samples: a small tile is the pair of two 2048-sample hops, a big tile the pair of two stretches of
+        // 16384 - halo16k samples -- the same m small tiles per big tile either way)
         const long long m = (16384 - a.halo16k) / 2048; // 2048-sample tiles per big tile
         const long long lo = a.halo16k / 2048 > a.t_lo ? a.halo16k / 2048 : a.t_lo;
         // worth it when the last round of one-tile-per-CU workgroups is full enough: per sample the big tile costs
@@ -928,7 +930,7 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
         const long long need = a.use16k == 2 ? 0 : a.parts == 2 ? 84 : 50;
         if (big >= 1 && big * a.channels * 100 >= rounds * cus * need) {
             a.big_tiles = big;
-            a.big_first = lo * 2048;
+            a.big_first = lo * per_tile;
             a.t_lo = lo;
             a.t_hi = lo + a.big_tiles * m;
         }
@@ -964,12 +966,14 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     a.grid_carry = (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64); // >= 1: every call carries
     if (a.big_tiles > 0) {
         // interior on the 16384-point kernel (one workgroup per CU); carry / edge workgroups behind it end the call
-        hipError_t e = launch_fir_fft16k_interior(a, a.cus16k > 0 ? a.cus16k : 256, stream);
+        hipError_t e = launch_fir_fft16k_interior(a, real, a.cus16k > 0 ? a.cus16k : 256, stream);
         if (e != hipSuccess) return e;
         const long long edge16 = (tiles_per_ch - inner) * a.channels;
         a.grid_edge = (int)(edge16 < 2048 ? edge16 : 2048);
         a.tickets = nullptr;
-        hipLaunchKernelGGL((fir_fft4096_short<false, false>), dim3((unsigned)(a.grid_carry + a.grid_edge)), dim3(256), 0, stream, a);
+        const dim3 gs((unsigned)(a.grid_carry + a.grid_edge));
+        if (real) hipLaunchKernelGGL((fir_fft4096_short<true, false>), gs, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((fir_fft4096_short<false, false>), gs, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
     if (a.gen.enabled) return a.gen.pstate ? launch_tiles<true, 2>(a, grid_int, stream) : launch_tiles<true, 1>(a, grid_int, stream);

@@ -24,12 +24,14 @@
 // [68 k1 + 17 k2 + c]: each conflict-free for its ds_write_b64 (16-lane groups, 32 banks) and its ds_read_b64
 // (32-lane groups, 64 banks), in both directions.
 //
-// Interior tiles only (complex samples); the call's carry / edge work runs as fir_fft4096_short behind it on the
+// Interior tiles only (complex samples, or real samples two stretches at a time); the call's carry / edge work runs as fir_fft4096_short behind it on the
 // stream -- the 4096-point partitioned form over the few 2048-sample tiles at both ends of every channel -- and
 // ends the call (history swap).  Tile boundaries are multiples of 2048 for that reason.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "fft_math.h"
 #include "fir_kernels.h"
@@ -50,6 +52,9 @@
 #endif
 #ifndef SDR16K_TA_REGS
 #define SDR16K_TA_REGS 1   // W_16384 twiddles in registers (1) or re-read from the L2-resident table at each use (0)
+#endif
+#ifndef SDR16K_XCD
+#define SDR16K_XCD 1       // a round of tiles dealt in contiguous runs per XCD, shared halo rows cacheable (1) or tile = blockIdx, all rows non-temporal (0)
 #endif
 #ifndef SDR16K_PREFETCH
 #define SDR16K_PREFETCH 1  // next tile's loads issued during the inverse transform (1) or at the top of its own tile (0)
@@ -404,7 +409,10 @@ __device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, cons
 // HROWS = halo / 1024 (4 or 8).  Tiles of a channel: big tile t (0 <= t < a.big_tiles) produces outputs
 // [a.big_first + t L, + L), L = 16384 - halo, reading 16384 inputs from a.big_first + t L - halo.  Workgroups walk
 // the flat list (channel, tile) grid-strided.
-template <int HROWS>
+// REAL: two stretches of a real stream ride as re / im of one complex transform (the filter is real-tap, hence
+// linear over that pairing), as in fir_fft4096: big tile t produces 2 L outputs from a.big_first + 2 t L, the re
+// member the first L of them, the im member the next L (its window starts L samples later).
+template <int HROWS, bool REAL>
 __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * PK + 1024];
     const int tid = threadIdx.x;
@@ -418,19 +426,50 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
     // grid-strided, and stride = dq big_tiles + dr is split once
     const int tiles = (int)a.big_tiles, channels = a.channels;
     if ((long long)blockIdx.x >= a.big_tiles * channels) return;
-    int ch = (int)(blockIdx.x / (unsigned)tiles), t = (int)(blockIdx.x % (unsigned)tiles);
+    // Neighbouring tiles share a halo of 4096 or 8192 samples (a third or all of what a tile reads).  Workgroups go
+    // to the eight XCDs round-robin by blockIdx, each XCD with an L2 of its own: with tile = blockIdx every halo was
+    // fetched through two L2s -- 1.36x the algorithmic reads at 4095 taps (profiles/r03_c3_summary.txt).  A round of
+    // the grid is dealt in eight contiguous runs instead, one per XCD, and the rows two tiles share are loaded with
+    // the default cache policy (the rest non-temporal): the neighbour finds them in its own XCD's L2.
+    unsigned first = blockIdx.x;
+#if SDR16K_XCD
+    if ((gridDim.x & 7u) == 0) first = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    int ch = (int)(first / (unsigned)tiles), t = (int)(first % (unsigned)tiles);
     int dq = (int)(gridDim.x / (unsigned)tiles), dr = (int)(gridDim.x % (unsigned)tiles);
     asm volatile("" : "+s"(dq), "+s"(dr));
     const int ch0 = ch, t0 = t;
-    auto in_of = [&](int chi, int ti) -> const f2* {
-        return reinterpret_cast<const f2*>(a.in) + chi * a.in_stride + a.big_first + ti * L - HALO;
+    typedef typename std::conditional<REAL, float, f2>::type S; // one sample in memory
+    constexpr long long PER_TILE = REAL ? 2 * L : L;
+    auto in_of = [&](int chi, int ti) -> const S* {
+        return reinterpret_cast<const S*>(a.in) + chi * a.in_stride + a.big_first + ti * PER_TILE - HALO;
     };
     unsigned lane = (unsigned)threadIdx.x;
+    // row r of a window: one complex sample per lane, or the pair (x[1024 r + lane], x[L + 1024 r + lane])
+    auto load_row = [&](const S* p, int r) -> f2 {
+        const bool shared = SDR16K_XCD && (r < HROWS || r >= 16 - HROWS); // also a row of the previous / next tile
+        if constexpr (REAL) {
+            const S* q0 = &(p + 1024 * r)[lane];
+            const S* q1 = &(p + (L + 1024 * r))[lane];
+            return shared ? f2{*q0, *q1} : f2{stream_load(q0), stream_load(q1)};
+        } else {
+            const S* q = &(p + 1024 * r)[lane];
+            return shared ? *q : stream_load(q);
+        }
+    };
+    auto store_row = [&](S* q, int r, f2 val) {
+        if constexpr (REAL) {
+            stream_store(val.x, &(q + 1024 * r)[lane]);
+            stream_store(val.y, &(q + (L + 1024 * r))[lane]);
+        } else {
+            stream_store(val, &(q + 1024 * r)[lane]);
+        }
+    };
     f2 nx[16];
     {
-        const f2* p = in_of(ch, t);
+        const S* p = in_of(ch, t);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nx[r] = stream_load(&(p + 1024 * r)[lane]);
+        for (int r = 0; r < 16; ++r) nx[r] = load_row(p, r);
     }
     Lane16k c;
     c.init(tid, reinterpret_cast<const f2*>(a.wtab16k), lds + 16 * PK);
@@ -444,9 +483,9 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         f2 v[16];
 #if !SDR16K_PREFETCH
         {
-            const f2* p = in_of(ch, t);
+            const S* p = in_of(ch, t);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nx[r] = stream_load(&(p + 1024 * r)[lane]);
+            for (int r = 0; r < 16; ++r) nx[r] = load_row(p, r);
         }
 #endif
 #pragma unroll
@@ -457,7 +496,7 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
             ++chn;
         }
         const bool more = chn < channels;
-        const f2* pn = more ? in_of(chn, tn) : in_of(ch0, t0); // past the end: a tile that sits in L2 (nobody consumes it)
+        const S* pn = more ? in_of(chn, tn) : in_of(ch0, t0); // past the end: a tile that sits in L2 (nobody consumes it)
         // the spectrum: L2-resident, requested ahead of the forward transform's last stage and AHEAD of the next tile's
         // prefetch (memory operations return in order)
         f2 h[16];
@@ -477,27 +516,27 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16k(k)], h[k]);
 #if SDR16K_PREFETCH
 #pragma unroll
-        for (int r = 0; r < 8; ++r) nx[r] = stream_load(&(pn + 1024 * r)[lane]);
+        for (int r = 0; r < 8; ++r) nx[r] = load_row(pn, r);
 #endif
-        f2* q0 = reinterpret_cast<f2*>(a.out) + ch * a.out_stride + a.big_first + t * L - HALO;
+        S* q0 = reinterpret_cast<S*>(a.out) + ch * a.out_stride + a.big_first + t * PER_TILE - HALO;
 #if SDR16K_STREAM
         inverse16k_s(w, lds, tid, c, [&] {
 #if SDR16K_PREFETCH
 #pragma unroll
-            for (int r = 8; r < 16; ++r) nx[r] = stream_load(&(pn + 1024 * r)[lane]);
+            for (int r = 8; r < 16; ++r) nx[r] = load_row(pn, r);
 #endif
         }, [&](int r, f2 val) {
-            if (r >= HROWS) stream_store(val, &(q0 + 1024 * r)[lane]);
+            if (r >= HROWS) store_row(q0, r, val);
         });
 #else
         inverse16k(w, lds, tid, c, [&] {
 #if SDR16K_PREFETCH
 #pragma unroll
-            for (int r = 8; r < 16; ++r) nx[r] = stream_load(&(pn + 1024 * r)[lane]);
+            for (int r = 8; r < 16; ++r) nx[r] = load_row(pn, r);
 #endif
         });
 #pragma unroll
-        for (int r = HROWS; r < 16; ++r) stream_store(w[P16k(r)], &(q0 + 1024 * r)[lane]);
+        for (int r = HROWS; r < 16; ++r) store_row(q0, r, w[P16k(r)]);
 #endif
         ch = chn;
         t = tn;
@@ -507,14 +546,20 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
 
 } // namespace
 
-hipError_t launch_fir_fft16k_interior(const FftArgs& a, int grid_blocks, hipStream_t stream) {
+hipError_t launch_fir_fft16k_interior(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream) {
     const long long total = a.big_tiles * a.channels;
     if (total <= 0) return hipSuccess;
     if (!a.hperm16k || !a.wtab16k || a.big_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 g((unsigned)(total < grid_blocks ? total : grid_blocks)), b(TK);
-    if (a.halo16k == 4096) hipLaunchKernelGGL((fir_fft16k<4>), g, b, 0, stream, a);
-    else if (a.halo16k == 8192) hipLaunchKernelGGL((fir_fft16k<8>), g, b, 0, stream, a);
-    else return hipErrorInvalidValue;
+    if (a.halo16k == 4096) {
+        if (real) hipLaunchKernelGGL((fir_fft16k<4, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((fir_fft16k<4, false>), g, b, 0, stream, a);
+    } else if (a.halo16k == 8192) {
+        if (real) hipLaunchKernelGGL((fir_fft16k<8, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((fir_fft16k<8, false>), g, b, 0, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ struct sdr_fir {
     bool fft_pair = false;
     int pair_halo = 0, pair_parts = 1, pair_grid = 0, pair_resident = 0;
     float* d_hperm_pair = nullptr; // spectra of the kept taps
-    // 16384-point kernel (fir_fft16k.hip): complex samples, 2050..8193 taps
+    // 16384-point kernel (fir_fft16k.hip): 2050..8193 taps
     int use16k = 0; // 0 no, 1 by the size of the call, 2 always (asked for by name)
     int halo16k = 0;
     float* d_hperm16k = nullptr;   // its one spectrum, then its twiddles
@@ -405,8 +405,9 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         f->fft_contig = env_int("SDR_AMD_FFT_CONTIG", 0);
 #endif
     }
-    // 16384-point tiles: complex samples, more than one and at most four 2048-tap partitions (2050..8193 taps)
-    if (use_fft && sample_kind == SDR_COMPLEX && fft_parts >= 2 && fft_parts <= 4 && path != SDR_PATH_FFT4K &&
+    // 16384-point tiles: more than one and at most four 2048-tap partitions (2050..8193 taps); real samples ride
+    // two stretches at a time (calls that take the complex-pair view of an every-other-tap design do not come here)
+    if (use_fft && fft_parts >= 2 && fft_parts <= 4 && path != SDR_PATH_FFT4K &&
         (path == SDR_PATH_FFT16K || SDR_FFT16K_AUTO)) {
         const int NK = 16384;
         std::vector<double> cs(NK), sn(NK), re(NK, 0.0), im(NK, 0.0);
@@ -715,7 +716,10 @@ extern "C" int sdr_fir_tap_stride(const sdr_fir_t* f) { return f ? (f->use_fft ?
 extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) {
     if (!f) return "";
     if (f->use_mfma) return fir_mfma_kernel_name(f->kind == SDR_REAL, f->k->stride);
-    if (f->use_fft && f->use16k) return f->use16k == 2 ? "fir_fft16k<COMPLEX>" : "fir_fft16k<COMPLEX> (short calls: fir_fft4096<COMPLEX>)";
+    if (f->use_fft && f->use16k && !f->fft_pair) {
+        if (f->kind == SDR_REAL) return f->use16k == 2 ? "fir_fft16k<REAL>" : "fir_fft16k<REAL> (short calls: fir_fft4096<REAL>)";
+        return f->use16k == 2 ? "fir_fft16k<COMPLEX>" : "fir_fft16k<COMPLEX> (short calls: fir_fft4096<COMPLEX>)";
+    }
     if (f->use_fft && f->fft_pair) return "fir_fft4096<REAL as complex pairs>";
     return f->use_fft ? fir_fft_kernel_name(f->kind == SDR_REAL) : f->k->name;
 }

@@ -97,29 +97,31 @@ def test_matrix_core_kernels(kind, ntaps, cplx):
         assert rel_err(y2[c], O.fir(taps, x2[c])) <= TOL, c
 
 
+@pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("ntaps", [2050, 4095, 4097, 4098, 6143, 8191, 8192])
-def test_16384_point_tiles_for_long_filters(ntaps):
+def test_16384_point_tiles_for_long_filters(ntaps, cplx):
     """fir_fft16k (one 16384-point tile holds a filter of 2050..8193 taps: halo 4096 or 8192, one spectrum, no
-    partitions; fir_fft16k.hip) pinned through the internal hook, complex samples: a stream long enough for many big
-    tiles, cut so that calls start and end inside, at and between tile boundaries (the 2048-sample tiles at both ends
-    of a call go to the 4096-point partitioned form), then three channels with a padded stride; and the same stream
-    through the 4096-point kernels alone agrees."""
+    partitions; fir_fft16k.hip) pinned through the internal hook, complex samples and real ones (two stretches of the
+    stream as re / im of one transform): a stream long enough for many big tiles, cut so that calls start and end
+    inside, at and between tile boundaries (the 2048-sample tiles at both ends of a call go to the 4096-point
+    partitioned form), then three channels with a padded stride; and the same stream through the 4096-point kernels
+    alone agrees."""
     rng = np.random.default_rng(ntaps)
     taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
-    n = 400001
-    x = rand(rng, n, True)
-    st = sdr_amd.FirState(taps, True, path="fft16k")
-    assert "fir_fft16k" in st.kernel_name, st.kernel_name
+    n = 400001 if cplx else 700001
+    x = rand(rng, n, cplx)
+    st = sdr_amd.FirState(taps, cplx, path="fft16k")
+    assert "fir_fft16k" in st.kernel_name and ("COMPLEX" if cplx else "REAL") in st.kernel_name, st.kernel_name
     cuts = [0, 5, 20000, 180000, 180001, 300000, n]
     y = np.concatenate([sdr_amd.fir(st, x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
     want = O.fir(taps, x)
     assert rel_err(y, want) <= TOL
-    st4 = sdr_amd.FirState(taps, True, path="fft4k")
+    st4 = sdr_amd.FirState(taps, cplx, path="fft4k")
     assert "fir_fft4096" in st4.kernel_name
     assert rel_err(sdr_amd.fir(st4, x), want) <= TOL
-    C, m = 3, 70001
-    x2 = np.stack([rand(rng, m, True) for _ in range(C)])
-    st2 = sdr_amd.FirState(taps, True, channels=C, path="fft16k")
+    C, m = 3, 70001 if cplx else 140001
+    x2 = np.stack([rand(rng, m, cplx) for _ in range(C)])
+    st2 = sdr_amd.FirState(taps, cplx, channels=C, path="fft16k")
     y2 = np.concatenate([sdr_amd.fir(st2, x2[:, :41000]), sdr_amd.fir(st2, x2[:, 41000:])], axis=1)
     for c in range(C):
         assert rel_err(y2[c], O.fir(taps, x2[c])) <= TOL, c
@@ -136,10 +138,12 @@ def test_kernel_family_chosen_by_measured_crossover():
     assert "fir_mfma" in name("hilbert", 63, False) and "fir_mfma" in name("hilbert", 95, True)
     assert "fir_fft4096" in name("lowpass", 65, True) and "fir_fft4096" in name("hilbert", 127, False)
     assert "fir_fft4096" in name("lowpass", 127, True) and "fir_fft4096" in name("bandpass", 2049, True)
-    # 2050..8192 taps on complex samples: 16384-point tiles when the call fills the chip with them
-    # (profiles/r03_long_taps_16k.txt), the partitioned 4096-point form for short calls and for real samples
+    # 2050..8192 taps: 16384-point tiles when the call fills the chip with them (profiles/r03_long_taps_16k.txt),
+    # the partitioned 4096-point form for short calls; an every-other-tap design on real samples stays on the
+    # complex-pair view of the 4096-point kernels
     assert "fir_fft16k" in name("bandpass", 4095, True) and "fir_fft16k" in name("bandpass", 8191, True)
-    assert "fir_fft16k" not in name("bandpass", 4095, False) and "fir_fft16k" not in name("bandpass", 8195, True)
+    assert "fir_fft16k<REAL>" in name("bandpass", 4095, False) and "fir_fft16k" not in name("bandpass", 8195, True)
+    assert "fir_fft16k" not in name("hilbert", 4095, False)
     assert "fir_mfma" not in name("hilbert", 61, False)      # kept taps on the odd phase
 
 
