@@ -38,6 +38,7 @@
 
 #include "fir_kernels.h"
 #include "fft_math.h"
+#include "fft_call.h"
 
 // shares the next tile's 16 row loads are issued in: 0 = one burst, 1 = three, 2 = six, 3 = eight
 #ifndef SDR_SPREAD
@@ -740,65 +741,6 @@ __device__ __forceinline__ void edge_tiles(const FftArgs& a, const float* hist_b
     }
 }
 
-// ---- history carry: after the call the other history buffer holds the last hist_len
-// samples of the virtual stream (old history | this call's input or synthesised samples).
-// Reads only what the call's other workgroups read; writes a buffer none of them touches.
-// Which buffer is which is device state (FirDevState::cur), flipped by call_done below.
-template <bool GEN>
-__device__ __forceinline__ void carry_history(const FftArgs& a, const float* old_hist, float* new_hist, const int w, const int bid,
-                                              const int nblk) {
-    const long long total = (long long)a.hist_len * w * a.channels;
-    for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
-        const long long ch = i / (a.hist_len * w);
-        const int r = (int)(i - ch * (a.hist_len * w));
-        const int s = r / w, k = r - s * w;
-        const long long m = a.n - a.hist_len + s;
-        float v;
-        if (m < 0) v = old_hist[(ch * a.hist_len + (a.hist_len + m)) * w + k];
-        else if constexpr (GEN) v = gen_src_at(a.gen, m);
-        else v = a.in[(ch * a.in_stride + m) * w + k];
-        new_hist[i] = v;
-    }
-}
-
-// ---- end of a call (every workgroup of the call's last launch, at its very end).  The workgroup that
-// finishes last leaves the handle's device state ready for the next launch on the stream: ticket
-// counters back to zero, history buffers swapped.  Nothing of this is host state, so a captured
-// graph of one call replays as the stream's next call (tests/test_graph_capture_gpu.py).
-// What it needs -- the state and ticket pointers -- it reads again from the kernel-argument segment through a
-// pointer the compiler cannot see through, instead of taking the caller's copies: values kept alive across the
-// persistent tile loop for this epilogue cost that loop scalar registers it does not have (it then re-loaded
-// `channels` from the argument segment in every tile, behind an s_waitcnt that also waits for the LDS: C2
-// 0.771 -> 0.798 ms, profiles/r03_device_state_ab.txt).  The kernels take FftArgs as their only parameter.
-__device__ __forceinline__ void call_done() {
-    __syncthreads(); // every wave of the workgroup is past its reads of the state, the history and its tickets
-    if (threadIdx.x == 0) {
-        const char __attribute__((address_space(4)))* ka =
-            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        FirDevState* const st = *reinterpret_cast<FirDevState* const __attribute__((address_space(4)))*>(ka + offsetof(FftArgs, state));
-        if (last_workgroup_done(st, gridDim.x)) {
-            unsigned* const tickets = *reinterpret_cast<unsigned* const __attribute__((address_space(4)))*>(ka + offsetof(FftArgs, tickets));
-            if (tickets) {
-#pragma unroll
-                for (int t = 0; t < FFT_TICKETS; ++t) tickets[FFT_TICKET_STRIDE * t] = 0;
-            }
-            st->done = 0;
-            st->cur = (st->cur & 1u) ^ 1u; // unchanged since the launch began: only this workgroup, here, writes it
-            // a fused generator with closed-form phases moves on by this call's blocks (GenSrc::pstate)
-            GenDevState* const gs = *reinterpret_cast<GenDevState* const __attribute__((address_space(4)))*>(
-                ka + offsetof(FftArgs, gen) + offsetof(GenSrc, pstate));
-            if (gs) {
-                const unsigned pincr = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(
-                    ka + offsetof(FftArgs, gen) + offsetof(GenSrc, pincr));
-                const unsigned nblocks = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(
-                    ka + offsetof(FftArgs, gen) + offsetof(GenSrc, nblocks));
-                gs->phase = (gs->phase + nblocks * pincr) & 0x7fffffu;
-            }
-        }
-    }
-}
-
 // ---- one launch per call.  The first a.grid_carry workgroups carry the history, the
 // next a.grid_edge take the edge tiles, the rest are the persistent interior
 // workgroups: the few slow, bounds-checked tiles start first and overlap the bulk
@@ -914,26 +856,24 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     const long long lead = a.parts > 1 ? (long long)a.parts * 2048 : a.halo;
     a.t_lo = (lead + per_tile - 1) / per_tile;
     a.t_hi = a.n / per_tile;
-    // 16384-point tiles for the interior (complex samples, two to four partitions' worth of taps): boundaries on
-    // multiples of 2048, so that the 4096-point partitioned form takes the few tiles left at both ends as edge tiles
-    a.big_tiles = 0;
+    // 16384-point tiles (two to four partitions' worth of taps: fir_fft16k.hip, the whole call in one launch of its
+    // own) when the call fills the chip with them: worth it when the last round of one-tile-per-CU workgroups is full
+    // enough -- per sample the big tile costs 0.84 of the cached two-partition form and about half of the three- and
+    // four-partition forms (use16k == 2: the caller asked for this path by name, every call takes it)
     if (a.use16k && !a.gen.enabled && a.parts >= 2 && a.parts <= 4 && a.hperm16k && a.halo16k >= 2048 * a.parts) {
-        // (real samples: a small tile is the pair of two 2048-sample hops, a big tile the pair of two stretches of
-        // 16384 - halo16k samples -- the same m small tiles per big tile either way)
-        const long long m = (16384 - a.halo16k) / 2048; // 2048-sample tiles per big tile
-        const long long lo = a.halo16k / 2048 > a.t_lo ? a.halo16k / 2048 : a.t_lo;
-        // worth it when the last round of one-tile-per-CU workgroups is full enough: per sample the big tile costs
-        // 0.84 of the cached two-partition form and about half of the three- and four-partition forms (use16k == 2:
-        // the caller asked for this path by name, any size that holds one tile takes it)
-        const long long big = (a.t_hi - lo) / m, cus = a.cus16k > 0 ? a.cus16k : 256;
+        long long P, big;
+        fir_fft16k_tiles(a.n, a.halo16k, real, &P, &big);
+        const long long cus = a.cus16k > 0 ? a.cus16k : 256;
         const long long rounds = (big * a.channels + cus - 1) / cus;
-        const long long need = a.use16k == 2 ? 0 : a.parts == 2 ? 84 : 50;
-        if (big >= 1 && big * a.channels * 100 >= rounds * cus * need) {
-            a.big_tiles = big;
-            a.big_first = lo * per_tile;
-            a.t_lo = lo;
-            a.t_hi = lo + a.big_tiles * m;
-        }
+        const long long need = a.parts == 2 ? 84 : 50;
+        // (its edge tiles run beside the bulk but cost ~40 us whatever the size: against the cached two-partition form
+        // it takes two rounds of tiles to be ahead, profiles/r03_fft16k_one_launch.txt)
+        // the three- and four-partition forms lose from 2^18 samples per call on, whatever the fill
+        // (profiles/r03_fft16k_one_launch.txt: 8191 taps, 0.033 against 0.042 ms at 2^18 samples)
+        const long long min_rounds = a.parts == 2 ? 2 : 1;
+        const bool long_enough = a.parts > 2 && a.n * a.channels >= (1LL << 18);
+        if (a.use16k == 2 || long_enough || (rounds >= min_rounds && big * a.channels * 100 >= rounds * cus * need))
+            return launch_fir_fft16k(a, real, (int)cus, stream);
     }
     const long long inner = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0;
     if (inner == 0) a.t_lo = a.t_hi = 0;
@@ -964,18 +904,6 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     a.grid_edge = (int)(edge < grid_blocks ? edge : grid_blocks);
     const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
     a.grid_carry = (int)((hist_elems + 255) / 256 < 64 ? (hist_elems + 255) / 256 : 64); // >= 1: every call carries
-    if (a.big_tiles > 0) {
-        // interior on the 16384-point kernel (one workgroup per CU); carry / edge workgroups behind it end the call
-        hipError_t e = launch_fir_fft16k_interior(a, real, a.cus16k > 0 ? a.cus16k : 256, stream);
-        if (e != hipSuccess) return e;
-        const long long edge16 = (tiles_per_ch - inner) * a.channels;
-        a.grid_edge = (int)(edge16 < 2048 ? edge16 : 2048);
-        a.tickets = nullptr;
-        const dim3 gs((unsigned)(a.grid_carry + a.grid_edge));
-        if (real) hipLaunchKernelGGL((fir_fft4096_short<true, false>), gs, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((fir_fft4096_short<false, false>), gs, dim3(256), 0, stream, a);
-        return hipGetLastError();
-    }
     if (a.gen.enabled) return a.gen.pstate ? launch_tiles<true, 2>(a, grid_int, stream) : launch_tiles<true, 1>(a, grid_int, stream);
     return real ? launch_tiles<true, 0>(a, grid_int, stream) : launch_tiles<false, 0>(a, grid_int, stream);
 }

@@ -24,9 +24,11 @@
 // [68 k1 + 17 k2 + c]: each conflict-free for its ds_write_b64 (16-lane groups, 32 banks) and its ds_read_b64
 // (32-lane groups, 64 banks), in both directions.
 //
-// Interior tiles only (complex samples, or real samples two stretches at a time); the call's carry / edge work runs as fir_fft4096_short behind it on the
-// stream -- the 4096-point partitioned form over the few 2048-sample tiles at both ends of every channel -- and
-// ends the call (history swap).  Tile boundaries are multiples of 2048 for that reason.
+// One launch per call: the interior tiles (complex samples, or real samples two stretches at a time) stream through
+// persistent workgroups, one per CU; the first tile of every channel (it reads the carried history), a partial last
+// one and the history carry go to a few workgroups at the end of the same grid, on CUs of their own, and the last
+// workgroup to finish ends the call (history swap).  (First build: those ran as fir_fft4096_short behind the main
+// kernel, 16-26 us of a 300 us call.)
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -35,6 +37,7 @@
 
 #include "fft_math.h"
 #include "fir_kernels.h"
+#include "fft_call.h"
 
 #ifndef SDR16K_FENCE
 #define SDR16K_FENCE 1     // scheduling fences behind each batch of LDS reads (1) or the compiler's own interleaving (0)
@@ -406,12 +409,76 @@ __device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, cons
     }
 }
 
-// HROWS = halo / 1024 (4 or 8).  Tiles of a channel: big tile t (0 <= t < a.big_tiles) produces outputs
-// [a.big_first + t L, + L), L = 16384 - halo, reading 16384 inputs from a.big_first + t L - halo.  Workgroups walk
-// the flat list (channel, tile) grid-strided.
+// Edge tiles: the first tile of every channel (its window reaches back into the carried history) and the last one when
+// it is partial (outputs or inputs beyond n).  The same transform pair over the virtual stream history | input | 0,
+// bounds-checked; a few workgroups at the END of the grid take them while the interior workgroups stream.
+template <int HROWS, bool REAL>
+__device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base, f2* lds, const Lane16k& c, const int tid,
+                                        const unsigned bid, const unsigned nblk) {
+    constexpr long long HALO = 1024LL * HROWS, L = NK - HALO, PT = REAL ? 2 * L : L;
+    constexpr int W = REAL ? 1 : 2;
+    const long long tiles_per_ch = (a.n + PT - 1) / PT;
+    const long long edge_per_ch = tiles_per_ch - a.big_tiles; // tile 0 and whatever follows the interior tiles 1..big_tiles
+    const long long total = edge_per_ch * a.channels;
+    const f2* const hbase = reinterpret_cast<const f2*>(a.hperm16k);
+    for (long long e = bid; e < total; e += nblk) {
+        const long long ch = e / edge_per_ch;
+        long long tt = e - ch * edge_per_ch;
+        if (tt >= 1) tt += a.big_tiles;
+        const float* in = a.in + ch * a.in_stride * W;
+        const float* hist = hist_base + ch * (long long)a.hist_len * W;
+        float* out = a.out + ch * a.out_stride * W;
+        const long long o0 = tt * PT; // first output of the tile
+        auto sample = [&](long long m, int k) -> float { // virtual stream: history | input | 0
+            if (m < 0) { const long long h = a.hist_len + m; return h >= 0 ? hist[h * W + k] : 0.0f; }
+            if (m >= a.n) return 0.0f;
+            return in[m * W + k];
+        };
+        // 1024 consecutive samples from m0 (wave-uniform): a row lies whole in the input or whole in the history except
+        // where it straddles an end of the stream -- uniform branches to plain coalesced loads, per-lane checks only there
+        auto stretch = [&](long long m0, int k) -> float {
+            if (m0 >= 0 && m0 + 1024 <= a.n) return in[(m0 + tid) * W + k];
+            if (m0 + 1024 <= 0 && a.hist_len + m0 >= 0) return hist[(a.hist_len + m0 + tid) * W + k];
+            return sample(m0 + tid, k);
+        };
+        f2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m0 = o0 - HALO + 1024 * r;
+            if (REAL) v[r] = f2{stretch(m0, 0), stretch(m0 + L, 0)};
+            else v[r] = f2{stretch(m0, 0), stretch(m0, 1)};
+            asm volatile("" : "+v"(v[r])); // one row at a time: sixteen rows of guarded loads at once spilled a hundred registers
+        }
+        f2 h[16];
+        forward16k_s(v, lds, tid, c, [&] {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) h[k] = (hbase + 1024 * k)[(unsigned)tid];
+        });
+        f2 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16k(k)], h[k]);
+        inverse16k_s(w, lds, tid, c, [] {}, [&](int r, f2 val) {
+            if (r < HROWS) return; // halo positions
+            const long long o = o0 - HALO + 1024 * r + tid;
+            if (REAL) {
+                if (o < a.n) out[o] = val.x;
+                if (o + L < a.n) out[o + L] = val.y;
+            } else if (o < a.n) {
+                *reinterpret_cast<f2*>(out + 2 * o) = val;
+            }
+        });
+    }
+}
+
+// HROWS = halo / 1024 (4 or 8).  One launch per call.  Tiles of a channel: tile t produces outputs [t P, t P + P),
+// P = L = 16384 - halo (REAL: 2 L), reading 16384 inputs from t P - halo.  Interior tiles -- every input and output
+// inside [0, n): tiles 1 .. a.big_tiles, tile t' = t - 1 starting at a.big_first + t' P with a.big_first = P -- are
+// walked by the first G workgroups of the grid, persistently; behind them come a.grid_edge workgroups for the edge
+// tiles and a.grid_carry for the history carry (G + edge + carry <= the CUs: one workgroup fills a CU, and every one
+// must be resident for the short work to overlap the bulk).  The last workgroup to finish ends the call (call_done).
 // REAL: two stretches of a real stream ride as re / im of one complex transform (the filter is real-tap, hence
-// linear over that pairing), as in fir_fft4096: big tile t produces 2 L outputs from a.big_first + 2 t L, the re
-// member the first L of them, the im member the next L (its window starts L samples later).
+// linear over that pairing), as in fir_fft4096: the re member produces the first L outputs of the tile, the im member
+// the next L (its window starts L samples later).
 template <int HROWS, bool REAL>
 __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
     __shared__ __align__(16) f2 lds[16 * PK + 1024];
@@ -422,21 +489,39 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
     switch ((tid >> 6) & 3) { case 0: __builtin_amdgcn_s_setprio(3); break; case 1: __builtin_amdgcn_s_setprio(2); break; case 2: __builtin_amdgcn_s_setprio(1); break; default: break; }
 #endif
     constexpr long long HALO = 1024LL * HROWS, L = NK - HALO;
+    const unsigned G = gridDim.x - (unsigned)a.grid_edge - (unsigned)a.grid_carry; // interior workgroups
+    if (blockIdx.x >= G) {
+        const unsigned sb = blockIdx.x - G;
+        const unsigned cur = a.state->cur & 1u;
+        if (sb < (unsigned)a.grid_edge) {
+            Lane16k c;
+            c.init(tid, reinterpret_cast<const f2*>(a.wtab16k), lds + 16 * PK);
+            __syncthreads(); // the twiddle table is read by other lanes than those that filled it (the interior loop's first read follows a block barrier anyway)
+            edge16k<HROWS, REAL>(a, pick(a.hist, cur), lds, c, tid, sb, (unsigned)a.grid_edge);
+        } else {
+            carry_history<false, TK>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, (int)(sb - (unsigned)a.grid_edge), a.grid_carry);
+        }
+        call_done();
+        return;
+    }
     // (channel, tile) of this workgroup's current and next tile, advanced without a division: the flat list is walked
     // grid-strided, and stride = dq big_tiles + dr is split once
     const int tiles = (int)a.big_tiles, channels = a.channels;
-    if ((long long)blockIdx.x >= a.big_tiles * channels) return;
     // Neighbouring tiles share a halo of 4096 or 8192 samples (a third or all of what a tile reads).  Workgroups go
     // to the eight XCDs round-robin by blockIdx, each XCD with an L2 of its own: with tile = blockIdx every halo was
-    // fetched through two L2s -- 1.36x the algorithmic reads at 4095 taps (profiles/r03_c3_summary.txt).  A round of
-    // the grid is dealt in eight contiguous runs instead, one per XCD, and the rows two tiles share are loaded with
-    // the default cache policy (the rest non-temporal): the neighbour finds them in its own XCD's L2.
+    // fetched through two L2s -- 1.36x the algorithmic reads at 4095 taps, 1.07x now (profiles/r03_c3_summary.txt).
+    // A round of the grid is dealt in eight contiguous runs instead, one per XCD (XCD x holds the workgroups
+    // blockIdx = x mod 8: G / 8 of them, one more for x < G mod 8), and the rows two tiles share are loaded with the
+    // default cache policy (the rest non-temporal): the neighbour finds them in its own XCD's L2.
     unsigned first = blockIdx.x;
 #if SDR16K_XCD
-    if ((gridDim.x & 7u) == 0) first = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    {
+        const unsigned x = blockIdx.x & 7u, q = G >> 3, rem = G & 7u;
+        first = x * q + (x < rem ? x : rem) + (blockIdx.x >> 3);
+    }
 #endif
     int ch = (int)(first / (unsigned)tiles), t = (int)(first % (unsigned)tiles);
-    int dq = (int)(gridDim.x / (unsigned)tiles), dr = (int)(gridDim.x % (unsigned)tiles);
+    int dq = (int)(G / (unsigned)tiles), dr = (int)(G % (unsigned)tiles);
     asm volatile("" : "+s"(dq), "+s"(dr));
     const int ch0 = ch, t0 = t;
     typedef typename std::conditional<REAL, float, f2>::type S; // one sample in memory
@@ -542,23 +627,54 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         t = tn;
         if (!more) break;
     }
+    call_done();
 }
 
 } // namespace
 
-hipError_t launch_fir_fft16k_interior(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream) {
-    const long long total = a.big_tiles * a.channels;
-    if (total <= 0) return hipSuccess;
-    if (!a.hperm16k || !a.wtab16k || a.big_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    const dim3 g((unsigned)(total < grid_blocks ? total : grid_blocks)), b(TK);
+// Tiles per channel and the interior ones among them for a call of n samples per channel (see fir_fft16k)
+void fir_fft16k_tiles(long long n, int halo16k, bool real, long long* per_tile, long long* interior) {
+    const long long P = (long long)(NK - halo16k) * (real ? 2 : 1);
+    *per_tile = P;
+    const long long full = n / P; // tiles whose outputs and inputs all lie below n: 0 .. full - 1; tile 0 reads the history
+    *interior = full > 1 ? full - 1 : 0;
+}
+
+// The whole call in one launch: interior, edge and carry workgroups (see fir_fft16k); `cus` = CUs of the device.
+hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t stream) {
+    if (a0.n <= 0 || a0.channels <= 0) return hipSuccess;
+    if (!a0.hperm16k || !a0.wtab16k || !a0.state || (a0.halo16k != 4096 && a0.halo16k != 8192)) return hipErrorInvalidValue;
+    FftArgs a = a0;
+    long long P, inner;
+    fir_fft16k_tiles(a.n, a.halo16k, real, &P, &inner);
+    if (inner > 0x7fffffffLL / (a.channels > 0 ? a.channels : 1)) return hipErrorInvalidValue; // 32-bit flat tile indices
+    const long long tiles_per_ch = (a.n + P - 1) / P;
+    a.big_tiles = inner;
+    a.big_first = P;
+    const long long total = inner * a.channels, edge = (tiles_per_ch - inner) * a.channels;
+    // the short work runs beside the bulk on CUs of its own: as few workgroups as finish it within the bulk's time
+    // (an edge tile costs about two interior ones), at most a quarter of the chip for a call that is all edges
+    const long long bulk_rounds = total > 0 ? (total + cus - 1) / cus : 1;
+    long long ge = (2 * edge + bulk_rounds - 1) / bulk_rounds;
+    if (ge > edge) ge = edge;
+    if (ge > cus / 4) ge = cus / 4;
+    if (ge < 1) ge = 1;
+    const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
+    long long gc = (hist_elems + TK * 8 - 1) / (TK * 8);
+    if (gc > 8) gc = 8;
+    if (gc < 1) gc = 1;
+    long long G = cus - ge - gc;
+    if (G > total) G = total;
+    if (G < 0) G = 0;
+    a.grid_edge = (int)ge;
+    a.grid_carry = (int)gc;
+    const dim3 g((unsigned)(G + ge + gc)), b(TK);
     if (a.halo16k == 4096) {
         if (real) hipLaunchKernelGGL((fir_fft16k<4, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((fir_fft16k<4, false>), g, b, 0, stream, a);
-    } else if (a.halo16k == 8192) {
+    } else {
         if (real) hipLaunchKernelGGL((fir_fft16k<8, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((fir_fft16k<8, false>), g, b, 0, stream, a);
-    } else {
-        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

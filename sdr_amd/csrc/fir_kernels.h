@@ -88,14 +88,15 @@ struct FftArgs {
     int resident;         // workgroups of the single-partition kernels resident on the device at once (0: unknown)
     // 16384-point kernel (fir_fft16k.hip; 2050..8193 taps): its spectrum (one, in that kernel's lane
     // order) and twiddles; use16k: the interior of every channel runs on it in tiles of 16384 - halo16k outputs
-    // (launch_fir_fft sets big_first / big_tiles and leaves the 2048-sample tiles at both ends to the edge workgroups)
+    // (launch_fir_fft16k sets big_first / big_tiles / grid_edge / grid_carry: one launch, edge and carry workgroups included)
     const float* hperm16k;
     const float* wtab16k;
     int use16k, halo16k, cus16k;
     long long big_first, big_tiles;
 };
 constexpr size_t FFT16K_TWIDDLE_COMPLEX = 16384 + 1024 + 64;
-hipError_t launch_fir_fft16k_interior(const FftArgs& a, bool real, int grid_blocks, hipStream_t stream);
+hipError_t launch_fir_fft16k(const FftArgs& a, bool real, int cus, hipStream_t stream);
+void fir_fft16k_tiles(long long n, int halo16k, bool real, long long* per_tile, long long* interior);
 void fir_fft16k_permute_spectrum(const float* h_natural, float* hperm); // 16384 complex
 void fir_fft16k_fill_twiddles(const double* cs, const double* sn, float* wtab);
 #ifndef SDR_FFT_TICKETS
