@@ -96,6 +96,9 @@
 #endif
 // Fused-generator kernels: the sine behind the (bit-exact) phase argument with fused multiply-adds (1,
 // gen_device.h: gen_sine_pair_fast, 13 operations per sample) or in the reference's own operation order (0, 18).
+#ifndef SDR_GEN_TBL
+#define SDR_GEN_TBL 1
+#endif
 #ifndef SDR_GEN_FAST
 #define SDR_GEN_FAST 1
 #endif
@@ -821,13 +824,14 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
     const dim3 g((unsigned)(grid_int + n_short));
     // W_256 twiddles from the LDS table: 161 VGPRs, three workgroups per CU (+3 % over
     // the all-register build at two per CU, profiles/r01_fft_variants.txt)
+    constexpr bool TBLK = GEN == 0 || SDR_GEN_TBL != 0; // W_256 twiddles: LDS table (three workgroups per CU) or registers (two)
     switch (a.halo / 64) {
-        case 1: hipLaunchKernelGGL((fir_fft4096<REAL, 1, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((fir_fft4096<REAL, 2, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((fir_fft4096<REAL, 4, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((fir_fft4096<REAL, 8, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 16: hipLaunchKernelGGL((fir_fft4096<REAL, 16, false, true, false, GEN>), g, b, 0, stream, a); break;
-        case 32: hipLaunchKernelGGL((fir_fft4096<REAL, 32, false, true, false, GEN>), g, b, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fir_fft4096<REAL, 1, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((fir_fft4096<REAL, 2, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((fir_fft4096<REAL, 4, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((fir_fft4096<REAL, 8, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 16: hipLaunchKernelGGL((fir_fft4096<REAL, 16, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 32: hipLaunchKernelGGL((fir_fft4096<REAL, 32, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
