@@ -127,6 +127,25 @@ def test_16384_point_tiles_for_long_filters(ntaps, cplx):
         assert rel_err(y2[c], O.fir(taps, x2[c])) <= TOL, c
 
 
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("ntaps", [4095, 8191])
+def test_16384_point_tiles_call_sizes(ntaps, cplx):
+    """fir_fft16k takes the whole call in one launch: calls of one sample, of less than a tile, of exactly one, two
+    and three tiles' worth of outputs, and one sample either side of those (the last tile is an edge tile exactly when
+    it is partial), as consecutive pieces of one stream."""
+    rng = np.random.default_rng(ntaps + cplx)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+    P = (16384 - (4096 if ntaps - 1 <= 4096 else 8192)) * (1 if cplx else 2)
+    sizes = [1, 100, P - 1, P, P + 1, 2 * P, 2 * P - 1, 3 * P, 3 * P + 1, 7]
+    x = rand(rng, sum(sizes), cplx)
+    st = sdr_amd.FirState(taps, cplx, path="fft16k")
+    out, at = [], 0
+    for m in sizes:
+        out.append(sdr_amd.fir(st, x[at:at + m]))
+        at += m
+    assert rel_err(np.concatenate(out), O.fir(taps, x)) <= TOL
+
+
 def test_kernel_family_chosen_by_measured_crossover():
     """sdr_fir_create picks the family by the measured three-way crossover
     (profiles/r02_direct_vs_fft_vs_mfma.txt): direct form up to 16 kept taps, the matrix-core

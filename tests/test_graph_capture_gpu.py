@@ -50,6 +50,8 @@ FAMILIES = [
     ("fft", sdr_amd.fir_lowpass, 127, False, 30001),     # odd length: the real kernel
     ("fft", None, 4095, True, 200000),                   # two partitions: cached spectrum, one launch
     ("fft", None, 9001, True, 60000),                    # five partitions: main launch + carry / edge launch
+    ("fft16k", None, 4095, True, 200000),                # 16384-point tiles: interior, edge and carry workgroups in one launch
+    ("fft16k", None, 6143, False, 150001),               # the same on real samples (two stretches per transform), halo 8192
 ]
 
 
