@@ -89,6 +89,8 @@ struct sdr_fir {
     int use16k = 0; // 0 no, 1 by the size of the call, 2 always (asked for by name)
     int halo16k = 0;
     float* d_hperm16k = nullptr;   // its one spectrum, then its twiddles
+    float* d_hperm16k_pair = nullptr; // the kept taps' spectrum for the complex-pair view of an every-other-tap design
+    int pair_halo16k = 0;
     const float* d_wtab16k = nullptr;
     int cus = 256;
     unsigned* d_tickets = nullptr; // tile-ticket counters behind the twiddle table (FftArgs::tickets): zero between calls
@@ -406,29 +408,45 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
 #endif
     }
     // 16384-point tiles: more than one and at most four 2048-tap partitions (2050..8193 taps); real samples ride
-    // two stretches at a time (calls that take the complex-pair view of an every-other-tap design do not come here)
-    if (use_fft && fft_parts >= 2 && fft_parts <= 4 && path != SDR_PATH_FFT4K &&
-        (path == SDR_PATH_FFT16K || SDR_FFT16K_AUTO)) {
+    // two stretches at a time; calls that take the complex-pair view of an every-other-tap design run the complex
+    // kernel with the spectrum of the kept taps (up to 8193 kept taps: a 16385-tap Hilbert design)
+    const bool want16k = use_fft && path != SDR_PATH_FFT4K && (path == SDR_PATH_FFT16K || SDR_FFT16K_AUTO);
+    const bool main16k = want16k && fft_parts >= 2 && fft_parts <= 4;
+    const bool pair16k = want16k && f->fft_pair && f->pair_parts >= 2 && f->pair_parts <= 4;
+    if (main16k || pair16k) {
         const int NK = 16384;
-        std::vector<double> cs(NK), sn(NK), re(NK, 0.0), im(NK, 0.0);
+        std::vector<double> cs(NK), sn(NK);
         for (int m = 0; m < NK; ++m) {
             cs[m] = std::cos(2.0 * M_PI * m / NK);
             sn[m] = std::sin(2.0 * M_PI * m / NK);
         }
-        for (size_t j = 0; j < ntaps; ++j) re[j] = taps[j];
-        fft_radix2(re, im, cs, sn);
-        std::vector<float> nat((size_t)2 * NK), hk((size_t)2 * NK + 2 * FFT16K_TWIDDLE_COMPLEX);
-        for (int k = 0; k < NK; ++k) {
-            nat[2 * k] = (float)(re[k] / NK);
-            nat[2 * k + 1] = (float)(im[k] / NK);
+        // spectrum H / N of `nt` taps in the kernel's lane order, followed (with_twiddles) by the twiddle tables
+        auto upload = [&](const float* t, size_t nt, bool with_twiddles, float** dst) -> hipError_t {
+            std::vector<double> re(NK, 0.0), im(NK, 0.0);
+            for (size_t j = 0; j < nt; ++j) re[j] = t[j];
+            fft_radix2(re, im, cs, sn);
+            std::vector<float> nat((size_t)2 * NK), hk((size_t)2 * NK + (with_twiddles ? 2 * FFT16K_TWIDDLE_COMPLEX : 0));
+            for (int k = 0; k < NK; ++k) {
+                nat[2 * k] = (float)(re[k] / NK);
+                nat[2 * k + 1] = (float)(im[k] / NK);
+            }
+            fir_fft16k_permute_spectrum(nat.data(), hk.data());
+            if (with_twiddles) fir_fft16k_fill_twiddles(cs.data(), sn.data(), hk.data() + (size_t)2 * NK);
+            hipError_t err = hipMalloc(dst, hk.size() * sizeof(float));
+            if (err != hipSuccess) return err;
+            return hipMemcpy(*dst, hk.data(), hk.size() * sizeof(float), hipMemcpyHostToDevice);
+        };
+        // (the twiddles live behind whichever spectrum comes first)
+        if (main16k) {
+            if ((e = upload(taps, ntaps, true, &f->d_hperm16k)) != hipSuccess) return bail(e, "16384-point spectrum");
+            f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK;
+            f->halo16k = ntaps - 1 <= 4096 ? 4096 : 8192;
         }
-        fir_fft16k_permute_spectrum(nat.data(), hk.data());
-        fir_fft16k_fill_twiddles(cs.data(), sn.data(), hk.data() + (size_t)2 * NK);
-        if ((e = hipMalloc(&f->d_hperm16k, hk.size() * sizeof(float))) != hipSuccess) return bail(e, "hipMalloc(spectrum)");
-        if ((e = hipMemcpy(f->d_hperm16k, hk.data(), hk.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)
-            return bail(e, "hipMemcpy(spectrum)");
-        f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK;
-        f->halo16k = ntaps - 1 <= 4096 ? 4096 : 8192;
+        if (pair16k) {
+            if ((e = upload(g.data(), plan.kept, !main16k, &f->d_hperm16k_pair)) != hipSuccess) return bail(e, "16384-point spectrum");
+            if (!main16k) f->d_wtab16k = f->d_hperm16k_pair + (size_t)2 * NK;
+            f->pair_halo16k = plan.kept - 1 <= 4096 ? 4096 : 8192;
+        }
         f->use16k = path == SDR_PATH_FFT16K ? 2 : 1;
     }
     if ((e = hipMemset(f->d_hist[0], 0, hist_bytes)) != hipSuccess) return bail(e, "hipMemset(history)");
@@ -488,6 +506,7 @@ extern "C" void sdr_fir_destroy(sdr_fir_t* f) {
     if (f->d_hperm) (void)hipFree(f->d_hperm);
     if (f->d_hperm_pair) (void)hipFree(f->d_hperm_pair);
     if (f->d_hperm16k) (void)hipFree(f->d_hperm16k);
+    if (f->d_hperm16k_pair) (void)hipFree(f->d_hperm16k_pair);
     if (f->d_hist[0]) (void)hipFree(f->d_hist[0]);
     if (f->d_hist[1]) (void)hipFree(f->d_hist[1]);
     if (f->d_state) (void)hipFree(f->d_state);
@@ -554,6 +573,13 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
             fa.hist_len = f->hist_len / 2;
             fa.parts = f->pair_parts;
             fa.resident = env_int("SDR_AMD_FFT_RESIDENT", f->pair_resident);
+            if (f->use16k && f->d_hperm16k_pair) {
+                fa.use16k = f->use16k;
+                fa.halo16k = f->pair_halo16k;
+                fa.hperm16k = f->d_hperm16k_pair;
+                fa.wtab16k = f->d_wtab16k;
+                fa.cus16k = f->cus;
+            }
             SDR_HIP(launch_fir_fft(fa, false, f->pair_grid, stream));
         } else {
             fa.hperm = f->d_hperm;
@@ -563,7 +589,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
             fa.halo = f->fft_halo;
             fa.hist_len = f->hist_len;
             fa.parts = f->fft_parts;
-            if (f->use16k) {
+            if (f->use16k && f->d_hperm16k) {
                 fa.use16k = f->use16k;
                 fa.halo16k = f->halo16k;
                 fa.hperm16k = f->d_hperm16k;
@@ -720,6 +746,8 @@ extern "C" const char* sdr_fir_kernel_name(const sdr_fir_t* f) {
         if (f->kind == SDR_REAL) return f->use16k == 2 ? "fir_fft16k<REAL>" : "fir_fft16k<REAL> (short calls: fir_fft4096<REAL>)";
         return f->use16k == 2 ? "fir_fft16k<COMPLEX>" : "fir_fft16k<COMPLEX> (short calls: fir_fft4096<COMPLEX>)";
     }
+    if (f->use_fft && f->fft_pair && f->use16k && f->d_hperm16k_pair)
+        return f->use16k == 2 ? "fir_fft16k<REAL as complex pairs>" : "fir_fft16k<REAL as complex pairs> (short calls: fir_fft4096<REAL as complex pairs>)";
     if (f->use_fft && f->fft_pair) return "fir_fft4096<REAL as complex pairs>";
     return f->use_fft ? fir_fft_kernel_name(f->kind == SDR_REAL) : f->k->name;
 }

@@ -146,6 +146,27 @@ def test_16384_point_tiles_call_sizes(ntaps, cplx):
     assert rel_err(np.concatenate(out), O.fir(taps, x)) <= TOL
 
 
+@pytest.mark.parametrize("ntaps", [8191, 16383])
+def test_16384_point_tiles_on_the_complex_pair_view(ntaps):
+    """A long Hilbert design on real samples: calls of even length take the complex view (x[2m], x[2m+1]) filtered by the
+    kept taps -- 4096 or 8192 of them: the 16384-point kernel with the kept taps' spectrum; odd calls in between take
+    the real kernels; both leave the same history."""
+    rng = np.random.default_rng(ntaps)
+    taps = sdr_amd.hilbert(ntaps)
+    st = sdr_amd.FirState(taps, False, path="fft16k")
+    assert "fir_fft16k<REAL as complex pairs>" in st.kernel_name, st.kernel_name
+    sizes = [200000, 3, 150001, 400000, 65536]
+    x = rand(rng, sum(sizes), False)
+    out, at = [], 0
+    for m in sizes:
+        out.append(sdr_amd.fir(st, x[at:at + m]))
+        at += m
+    assert rel_err(np.concatenate(out), O.fir(taps, x)) <= TOL
+    auto = sdr_amd.FirState(taps, False)
+    assert "fir_fft16k<REAL as complex pairs> (short calls" in auto.kernel_name
+    assert rel_err(sdr_amd.fir(auto, x), O.fir(taps, x)) <= TOL
+
+
 def test_kernel_family_chosen_by_measured_crossover():
     """sdr_fir_create picks the family by the measured three-way crossover
     (profiles/r02_direct_vs_fft_vs_mfma.txt): direct form up to 16 kept taps, the matrix-core
