@@ -100,7 +100,10 @@ void fir_fft16k_tiles(long long n, int halo16k, bool real, long long* per_tile, 
 void fir_fft16k_permute_spectrum(const float* h_natural, float* hperm); // 16384 complex
 void fir_fft16k_fill_twiddles(const double* cs, const double* sn, float* wtab);
 #ifndef SDR_FFT_TICKETS
-#define SDR_FFT_TICKETS 2 // measured 2 / 8 / 32: C2 0.789 / 0.795 / 0.808 ms (one counter serialises at ~12 ns per ticket: too slow)
+// measured (profiles/r03_ticket_counters.txt): 1 counter serialises (C2 0.858 ms), 2 / 4 / 6: 0.776 / 0.779 / 0.779, 3 / 5 / 7 / 9: 0.765 /
+// 0.769 / 0.775 / 0.777.  Three: the three workgroups resident on a CU (block ids 256 apart: three different residues mod 3) draw from
+// three different counters, so a CU's tiles in flight are neighbours in memory; with an even count they all share one counter.
+#define SDR_FFT_TICKETS 3
 #endif
 constexpr int FFT_TICKETS = SDR_FFT_TICKETS;
 constexpr int FFT_TICKET_STRIDE = 64;
