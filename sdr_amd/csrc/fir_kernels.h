@@ -101,8 +101,9 @@ void fir_fft16k_permute_spectrum(const float* h_natural, float* hperm); // 16384
 void fir_fft16k_fill_twiddles(const double* cs, const double* sn, float* wtab);
 #ifndef SDR_FFT_TICKETS
 // measured (profiles/r03_ticket_counters.txt): 1 counter serialises (C2 0.858 ms), 2 / 4 / 6: 0.776 / 0.779 / 0.779, 3 / 5 / 7 / 9: 0.765 /
-// 0.769 / 0.775 / 0.777.  Three: the three workgroups resident on a CU (block ids 256 apart: three different residues mod 3) draw from
-// three different counters, so a CU's tiles in flight are neighbours in memory; with an even count they all share one counter.
+// 0.769 / 0.775 / 0.777: odd counts beat even ones, three is best (and the counter must be bid % 3: (bid >> 3) % 3 loses 2.7 %, two
+// counters chosen by bid >> 3 or bid >> 8 lose 1 % / 11 %).  With bid % 3 a workgroup's tiles all have one residue mod 3 (the grid, 768, is a
+// multiple of 3) and every XCD (bid % 8) holds an equal mix of the three sequences; the mechanism behind the odd / even split was not isolated.
 #define SDR_FFT_TICKETS 3
 #endif
 constexpr int FFT_TICKETS = SDR_FFT_TICKETS;
