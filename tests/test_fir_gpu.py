@@ -479,6 +479,26 @@ def test_non_finite_sample_stays_local(path, ntaps, reach, bad):
     assert rel_err(y[keep], want[keep]) <= TOL
 
 
+@pytest.mark.parametrize("cplx,reach", [(True, 16384), (False, 32768)])
+def test_non_finite_sample_in_a_16384_point_tile(cplx, reach):
+    """The 16384-point kernel loses the tile a NaN sits in (real samples: the two stretches that share the transform),
+    nothing else (INTEGRATION.md)."""
+    rng = np.random.default_rng(5)
+    ntaps = 4095
+    taps = taps_for("bandpass", ntaps)
+    n, p = (200000, 100000) if cplx else (400000, 200000)
+    x = rand(rng, n, cplx)
+    x[p] = np.nan
+    st = sdr_amd.FirState(taps, cplx, path="fft16k")
+    y = sdr_amd.fir(st, x)
+    want = O.fir(taps, x)
+    assert not np.isfinite(y[p:p + ntaps]).any()
+    lo, hi = p - reach, p + ntaps + reach
+    assert np.isfinite(y[:lo]).all() and np.isfinite(y[hi:]).all()
+    keep = np.r_[0:lo, hi:n]
+    assert rel_err(y[keep], want[keep]) <= TOL
+
+
 @pytest.mark.parametrize("kind,ntaps,cplx,family", [("hilbert", 127, False, "fir_direct"), ("lowpass", 127, True, "fir_direct"),
                                                     ("lowpass", 31, True, "fir_mfma"), ("bandpass", 4095, True, "fir_direct")])
 def test_per_output_numerics(kind, ntaps, cplx, family):
