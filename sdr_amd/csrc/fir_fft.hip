@@ -864,9 +864,9 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     // own) when the call fills the chip with them: worth it when the last round of one-tile-per-CU workgroups is full
     // enough -- per sample the big tile costs 0.84 of the cached two-partition form and about half of the three- and
     // four-partition forms (use16k == 2: the caller asked for this path by name, every call takes it)
-    if (a.use16k && !a.gen.enabled && a.parts >= 2 && a.parts <= 4 && a.hperm16k && a.halo16k >= 2048 * a.parts) {
-        long long P, big;
-        fir_fft16k_tiles(a.n, a.halo16k, real, &P, &big);
+    if (a.use16k && !a.gen.enabled && a.parts >= 2 && a.hperm16k) { // (halo16k / parts16 cover the taps: sdr_capi.hip)
+        long long P, first, big;
+        fir_fft16k_tiles(a.n, a.halo16k, real, a.parts16 > 1 ? a.parts16 : 1, &P, &first, &big);
         const long long cus = a.cus16k > 0 ? a.cus16k : 256;
         const long long rounds = (big * a.channels + cus - 1) / cus;
         const long long need = a.parts == 2 ? 84 : 50;

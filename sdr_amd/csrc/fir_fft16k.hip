@@ -420,19 +420,20 @@ __device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, cons
 // Edge tiles: the first tile of every channel (its window reaches back into the carried history) and the last one when
 // it is partial (outputs or inputs beyond n).  The same transform pair over the virtual stream history | input | 0,
 // bounds-checked; a few workgroups at the END of the grid take them while the interior workgroups stream.
-template <int HROWS, bool REAL>
+template <int HROWS, bool REAL, bool LONG16>
 __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base, f2* lds, const Lane16k& c, const int tid,
                                         const unsigned bid, const unsigned nblk) {
     constexpr long long HALO = 1024LL * HROWS, L = NK - HALO, PT = REAL ? 2 * L : L;
     constexpr int W = REAL ? 1 : 2;
     const long long tiles_per_ch = (a.n + PT - 1) / PT;
-    const long long edge_per_ch = tiles_per_ch - a.big_tiles; // tile 0 and whatever follows the interior tiles 1..big_tiles
+    const long long edge_per_ch = tiles_per_ch - a.big_tiles; // the tiles before the first interior one and whatever follows the last
     const long long total = edge_per_ch * a.channels;
+    const long long t_first = a.big_first / PT;                // first interior tile
     const f2* const hbase = reinterpret_cast<const f2*>(a.hperm16k);
     for (long long e = bid; e < total; e += nblk) {
         const long long ch = e / edge_per_ch;
         long long tt = e - ch * edge_per_ch;
-        if (tt >= 1) tt += a.big_tiles;
+        if (tt >= t_first) tt += a.big_tiles;
         const float* in = a.in + ch * a.in_stride * W;
         const float* hist = hist_base + ch * (long long)a.hist_len * W;
         float* out = a.out + ch * a.out_stride * W;
@@ -450,13 +451,16 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
             return sample(m0 + tid, k);
         };
         f2 v[16];
+        auto window = [&](long long back) { // the tile's window, `back` samples earlier
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long m0 = o0 - HALO + 1024 * r;
-            if (REAL) v[r] = f2{stretch(m0, 0), stretch(m0 + L, 0)};
-            else v[r] = f2{stretch(m0, 0), stretch(m0, 1)};
-            asm volatile("" : "+v"(v[r])); // one row at a time: sixteen rows of guarded loads at once spilled a hundred registers
-        }
+            for (int r = 0; r < 16; ++r) {
+                const long long m0 = o0 - HALO - back + 1024 * r;
+                if (REAL) v[r] = f2{stretch(m0, 0), stretch(m0 + L, 0)};
+                else v[r] = f2{stretch(m0, 0), stretch(m0, 1)};
+                asm volatile("" : "+v"(v[r])); // one row at a time: sixteen rows of guarded loads at once spilled a hundred registers
+            }
+        };
+        window(0);
         f2 h[16];
         forward16k_s(v, lds, tid, c, [&] {
 #pragma unroll
@@ -465,6 +469,16 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
         f2 w[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16k(k)], h[k]);
+        if constexpr (LONG16) {
+            for (int p = 1; p < a.parts16; ++p) { // Y_b = sum_p X_(b-p) H_p, hop 8192
+                window(8192LL * p);
+                __syncthreads(); // the previous transform was a forward one too: its last stage still reads rows this one's first stage writes
+                forward16k_s(v, lds, tid, c, [] {});
+                const f2* const hp = hbase + (size_t)p * NK;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) w[k] += cmul(v[P16k(k)], (hp + 1024 * k)[(unsigned)tid]);
+            }
+        }
         inverse16k_s(w, lds, tid, c, [] {}, [&](int r, f2 val) {
             if (r < HROWS) return; // halo positions
             const long long o = o0 - HALO + 1024 * r + tid;
@@ -487,8 +501,14 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
 // REAL: two stretches of a real stream ride as re / im of one complex transform (the filter is real-tap, hence
 // linear over that pairing), as in fir_fft4096: the re member produces the first L outputs of the tile, the im member
 // the next L (its window starts L samples later).
-template <int HROWS, bool REAL>
+// LONG16 (HROWS = 8): uniformly partitioned overlap-save for more than 8193 taps -- hop 8192, the filter cut into a.parts16
+// pieces of 8192 taps, Y_b = sum_p X_(b-p) H_p: the windows b-1.. are re-read (L2 / Infinity Cache) and re-transformed, the
+// spectra H_p come from L2 (a.hperm16k holds them back to back).  (parts + 1) transforms of 16384 points per 8192 outputs where
+// the 4096-point partitioned form runs (4 parts + 1) of 4096 points per 2048: 0.35-0.4 of its arithmetic.  No register prefetch
+// of the next tile in this variant: the product accumulators take its place.
+template <int HROWS, bool REAL, bool LONG16 = false>
 __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
+    static_assert(!LONG16 || HROWS == 8, "the partitioned form hops 8192 samples");
     __shared__ __align__(16) f2 lds[16 * PK + 1024];
     const int tid = threadIdx.x;
 #if SDR16K_PRIO == 1
@@ -505,7 +525,7 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
             Lane16k c;
             c.init(tid, reinterpret_cast<const f2*>(a.wtab16k), lds + 16 * PK);
             __syncthreads(); // the twiddle table is read by other lanes than those that filled it (the interior loop's first read follows a block barrier anyway)
-            edge16k<HROWS, REAL>(a, pick(a.hist, cur), lds, c, tid, sb, (unsigned)a.grid_edge);
+            edge16k<HROWS, REAL, LONG16>(a, pick(a.hist, cur), lds, c, tid, sb, (unsigned)a.grid_edge);
         } else {
             carry_history<false, TK>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, (int)(sb - (unsigned)a.grid_edge), a.grid_carry);
         }
@@ -558,8 +578,9 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
             stream_store(val, &(q + 1024 * r)[lane]);
         }
     };
+    constexpr bool PREFETCH = SDR16K_PREFETCH && !LONG16;
     f2 nx[16];
-    {
+    if constexpr (PREFETCH) {
         const S* p = in_of(ch, t);
 #pragma unroll
         for (int r = 0; r < 16; ++r) nx[r] = load_row(p, r);
@@ -574,15 +595,14 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         // were sixteen 64-bit registers that went straight to scratch)
         asm volatile("" : "+v"(lane));
         f2 v[16];
-#if !SDR16K_PREFETCH
-        {
+        if constexpr (!PREFETCH) {
             const S* p = in_of(ch, t);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nx[r] = load_row(p, r);
-        }
-#endif
+            for (int r = 0; r < 16; ++r) v[r] = load_row(p, r);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = nx[i];
+            for (int i = 0; i < 16; ++i) v[i] = nx[i];
+        }
         int chn = ch + dq, tn = t + dr;
         if (tn >= tiles) {
             tn -= tiles;
@@ -607,31 +627,55 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         f2 w[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) w[k] = cmul(v[P16k(k)], h[k]);
-#if SDR16K_PREFETCH
+        if constexpr (LONG16) {
+            for (int p = 1; p < a.parts16; ++p) { // window b-p: every row was read before (by this or a neighbouring tile)
+                const S* pw = in_of(ch, t) - 8192LL * p;
 #pragma unroll
-        for (int r = 0; r < SDR16K_PF_FIRST; ++r) nx[r] = load_row(pn, r);
-#endif
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (REAL) v[r] = f2{(pw + 1024 * r)[lane], (pw + (L + 1024 * r))[lane]};
+                    else v[r] = (pw + 1024 * r)[lane];
+                }
+                // the previous transform was a forward one too: other waves' last stage may still read the rows this one's
+                // first stage writes (after an inverse transform its block barrier has seen to that)
+                __syncthreads();
+                forward16k_s(v, lds, tid, c, [] {});
+                const f2* const hp = hbase + (size_t)p * NK;
+                // the spectrum a quarter at a time: the accumulators leave no room for sixteen rows of it
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f2 hq[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hq[i] = (hp + 1024 * (4 * g4 + i))[lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[4 * g4 + i] += cmul(v[P16k(4 * g4 + i)], hq[i]);
+                }
+            }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int r = 0; r < SDR16K_PF_FIRST; ++r) nx[r] = load_row(pn, r);
+        }
         S* q0 = reinterpret_cast<S*>(a.out) + ch * a.out_stride + a.big_first + t * PER_TILE - HALO;
 #if SDR16K_STREAM
         inverse16k_s(w, lds, tid, c, [&] {
-#if SDR16K_PREFETCH
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int r = SDR16K_PF_SECOND; r < 16; ++r) nx[r] = load_row(pn, r);
-#endif
+                for (int r = SDR16K_PF_SECOND; r < 16; ++r) nx[r] = load_row(pn, r);
+            }
         }, [&](int r, f2 val) {
             if (r >= HROWS) store_row(q0, r, val);
         }, [&] {
-#if SDR16K_PREFETCH
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int r = SDR16K_PF_FIRST; r < SDR16K_PF_SECOND; ++r) nx[r] = load_row(pn, r);
-#endif
+                for (int r = SDR16K_PF_FIRST; r < SDR16K_PF_SECOND; ++r) nx[r] = load_row(pn, r);
+            }
         });
 #else
         inverse16k(w, lds, tid, c, [&] {
-#if SDR16K_PREFETCH
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int r = SDR16K_PF_FIRST; r < 16; ++r) nx[r] = load_row(pn, r);
-#endif
+                for (int r = SDR16K_PF_FIRST; r < 16; ++r) nx[r] = load_row(pn, r);
+            }
         });
 #pragma unroll
         for (int r = HROWS; r < 16; ++r) store_row(q0, r, w[P16k(r)]);
@@ -645,25 +689,30 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
 
 } // namespace
 
-// Tiles per channel and the interior ones among them for a call of n samples per channel (see fir_fft16k)
-void fir_fft16k_tiles(long long n, int halo16k, bool real, long long* per_tile, long long* interior) {
+// For a call of n samples per channel: outputs per tile, the first interior tile and how many interior tiles follow it (see
+// fir_fft16k; parts16 > 1: the partitioned form, whose interior windows reach (parts16 - 1) * 8192 samples further back)
+void fir_fft16k_tiles(long long n, int halo16k, bool real, int parts16, long long* per_tile, long long* first, long long* interior) {
     const long long P = (long long)(NK - halo16k) * (real ? 2 : 1);
     *per_tile = P;
-    const long long full = n / P; // tiles whose outputs and inputs all lie below n: 0 .. full - 1; tile 0 reads the history
-    *interior = full > 1 ? full - 1 : 0;
+    const long long reach = halo16k + (parts16 > 1 ? (long long)(parts16 - 1) * 8192 : 0);
+    const long long t_first = (reach + P - 1) / P; // first tile whose oldest window starts at a sample >= 0
+    const long long full = n / P;                  // tiles whose outputs and inputs all lie below n: 0 .. full - 1
+    *first = t_first;
+    *interior = full > t_first ? full - t_first : 0;
 }
 
 // The whole call in one launch: interior, edge and carry workgroups (see fir_fft16k); `cus` = CUs of the device.
 hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t stream) {
     if (a0.n <= 0 || a0.channels <= 0) return hipSuccess;
     if (!a0.hperm16k || !a0.wtab16k || !a0.state || (a0.halo16k != 4096 && a0.halo16k != 8192)) return hipErrorInvalidValue;
+    if (a0.parts16 > 1 && a0.halo16k != 8192) return hipErrorInvalidValue;
     FftArgs a = a0;
-    long long P, inner;
-    fir_fft16k_tiles(a.n, a.halo16k, real, &P, &inner);
+    long long P, t_first, inner;
+    fir_fft16k_tiles(a.n, a.halo16k, real, a.parts16, &P, &t_first, &inner);
     if (inner > 0x7fffffffLL / (a.channels > 0 ? a.channels : 1)) return hipErrorInvalidValue; // 32-bit flat tile indices
     const long long tiles_per_ch = (a.n + P - 1) / P;
     a.big_tiles = inner;
-    a.big_first = P;
+    a.big_first = t_first * P;
     const long long total = inner * a.channels, edge = (tiles_per_ch - inner) * a.channels;
     // the short work runs beside the bulk on CUs of its own: as few workgroups as finish it within the bulk's time
     // (an edge tile costs about two interior ones), at most a quarter of the chip for a call that is all edges
@@ -685,6 +734,9 @@ hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t 
     if (a.halo16k == 4096) {
         if (real) hipLaunchKernelGGL((fir_fft16k<4, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((fir_fft16k<4, false>), g, b, 0, stream, a);
+    } else if (a.parts16 > 1) {
+        if (real) hipLaunchKernelGGL((fir_fft16k<8, true, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((fir_fft16k<8, false, true>), g, b, 0, stream, a);
     } else {
         if (real) hipLaunchKernelGGL((fir_fft16k<8, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((fir_fft16k<8, false>), g, b, 0, stream, a);

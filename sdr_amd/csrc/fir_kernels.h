@@ -92,11 +92,12 @@ struct FftArgs {
     const float* hperm16k;
     const float* wtab16k;
     int use16k, halo16k, cus16k;
+    int parts16;          // > 1: more than 8193 taps, partitions of 8192 taps (hperm16k holds parts16 spectra back to back)
     long long big_first, big_tiles;
 };
 constexpr size_t FFT16K_TWIDDLE_COMPLEX = 16384 + 1024 + 64;
 hipError_t launch_fir_fft16k(const FftArgs& a, bool real, int cus, hipStream_t stream);
-void fir_fft16k_tiles(long long n, int halo16k, bool real, long long* per_tile, long long* interior);
+void fir_fft16k_tiles(long long n, int halo16k, bool real, int parts16, long long* per_tile, long long* first, long long* interior);
 void fir_fft16k_permute_spectrum(const float* h_natural, float* hperm); // 16384 complex
 void fir_fft16k_fill_twiddles(const double* cs, const double* sn, float* wtab);
 #ifndef SDR_FFT_TICKETS

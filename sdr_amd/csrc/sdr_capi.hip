@@ -91,6 +91,7 @@ struct sdr_fir {
     float* d_hperm16k = nullptr;   // its one spectrum, then its twiddles
     float* d_hperm16k_pair = nullptr; // the kept taps' spectrum for the complex-pair view of an every-other-tap design
     int pair_halo16k = 0;
+    int parts16 = 1;               // > 1: more than 8193 taps, partitions of 8192 taps
     const float* d_wtab16k = nullptr;
     int cus = 256;
     unsigned* d_tickets = nullptr; // tile-ticket counters behind the twiddle table (FftArgs::tickets): zero between calls
@@ -411,7 +412,9 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // two stretches at a time; calls that take the complex-pair view of an every-other-tap design run the complex
     // kernel with the spectrum of the kept taps (up to 8193 kept taps: a 16385-tap Hilbert design)
     const bool want16k = use_fft && path != SDR_PATH_FFT4K && (path == SDR_PATH_FFT16K || SDR_FFT16K_AUTO);
-    const bool main16k = want16k && fft_parts >= 2 && fft_parts <= 4;
+    // (beyond 8193 taps: 16384-point tiles partitioned at 8192 taps, up to 16 partitions = 131072 taps)
+    const bool main16k = want16k && fft_parts >= 2;
+    const int parts16 = ntaps - 1 <= 8192 ? 1 : (int)((ntaps + 8191) / 8192);
     const bool pair16k = want16k && f->fft_pair && f->pair_parts >= 2 && f->pair_parts <= 4;
     if (main16k || pair16k) {
         const int NK = 16384;
@@ -420,30 +423,36 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
             cs[m] = std::cos(2.0 * M_PI * m / NK);
             sn[m] = std::sin(2.0 * M_PI * m / NK);
         }
-        // spectrum H / N of `nt` taps in the kernel's lane order, followed (with_twiddles) by the twiddle tables
-        auto upload = [&](const float* t, size_t nt, bool with_twiddles, float** dst) -> hipError_t {
-            std::vector<double> re(NK, 0.0), im(NK, 0.0);
-            for (size_t j = 0; j < nt; ++j) re[j] = t[j];
-            fft_radix2(re, im, cs, sn);
-            std::vector<float> nat((size_t)2 * NK), hk((size_t)2 * NK + (with_twiddles ? 2 * FFT16K_TWIDDLE_COMPLEX : 0));
-            for (int k = 0; k < NK; ++k) {
-                nat[2 * k] = (float)(re[k] / NK);
-                nat[2 * k + 1] = (float)(im[k] / NK);
+        // spectra H_p / N of `nt` taps cut into `np` pieces (one piece: all of them; else 8192 taps each) in the kernel's lane
+        // order, back to back, followed (with_twiddles) by the twiddle tables
+        auto upload = [&](const float* t, size_t nt, int np, bool with_twiddles, float** dst) -> hipError_t {
+            std::vector<float> nat((size_t)2 * NK), hk((size_t)2 * NK * np + (with_twiddles ? 2 * FFT16K_TWIDDLE_COMPLEX : 0));
+            const size_t plen = np > 1 ? 8192 : nt;
+            for (int p = 0; p < np; ++p) {
+                std::vector<double> re(NK, 0.0), im(NK, 0.0);
+                const size_t j0 = (size_t)p * plen, j1 = std::min(nt, j0 + plen);
+                for (size_t j = j0; j < j1; ++j) re[j - j0] = t[j];
+                fft_radix2(re, im, cs, sn);
+                for (int k = 0; k < NK; ++k) {
+                    nat[2 * k] = (float)(re[k] / NK);
+                    nat[2 * k + 1] = (float)(im[k] / NK);
+                }
+                fir_fft16k_permute_spectrum(nat.data(), hk.data() + (size_t)2 * NK * p);
             }
-            fir_fft16k_permute_spectrum(nat.data(), hk.data());
-            if (with_twiddles) fir_fft16k_fill_twiddles(cs.data(), sn.data(), hk.data() + (size_t)2 * NK);
+            if (with_twiddles) fir_fft16k_fill_twiddles(cs.data(), sn.data(), hk.data() + (size_t)2 * NK * np);
             hipError_t err = hipMalloc(dst, hk.size() * sizeof(float));
             if (err != hipSuccess) return err;
             return hipMemcpy(*dst, hk.data(), hk.size() * sizeof(float), hipMemcpyHostToDevice);
         };
         // (the twiddles live behind whichever spectrum comes first)
         if (main16k) {
-            if ((e = upload(taps, ntaps, true, &f->d_hperm16k)) != hipSuccess) return bail(e, "16384-point spectrum");
-            f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK;
+            if ((e = upload(taps, ntaps, parts16, true, &f->d_hperm16k)) != hipSuccess) return bail(e, "16384-point spectrum");
+            f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK * parts16;
             f->halo16k = ntaps - 1 <= 4096 ? 4096 : 8192;
+            f->parts16 = parts16;
         }
         if (pair16k) {
-            if ((e = upload(g.data(), plan.kept, !main16k, &f->d_hperm16k_pair)) != hipSuccess) return bail(e, "16384-point spectrum");
+            if ((e = upload(g.data(), plan.kept, 1, !main16k, &f->d_hperm16k_pair)) != hipSuccess) return bail(e, "16384-point spectrum");
             if (!main16k) f->d_wtab16k = f->d_hperm16k_pair + (size_t)2 * NK;
             f->pair_halo16k = plan.kept - 1 <= 4096 ? 4096 : 8192;
         }
@@ -576,6 +585,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
             if (f->use16k && f->d_hperm16k_pair) {
                 fa.use16k = f->use16k;
                 fa.halo16k = f->pair_halo16k;
+                fa.parts16 = 1;
                 fa.hperm16k = f->d_hperm16k_pair;
                 fa.wtab16k = f->d_wtab16k;
                 fa.cus16k = f->cus;
@@ -592,6 +602,7 @@ static int process_device_impl(sdr_fir* f, const float* d_in, size_t in_stride, 
             if (f->use16k && f->d_hperm16k) {
                 fa.use16k = f->use16k;
                 fa.halo16k = f->halo16k;
+                fa.parts16 = f->parts16;
                 fa.hperm16k = f->d_hperm16k;
                 fa.wtab16k = f->d_wtab16k;
                 fa.cus16k = f->cus; // one 1024-lane workgroup per CU

@@ -128,6 +128,30 @@ def test_16384_point_tiles_for_long_filters(ntaps, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("ntaps", [8194, 9001, 16383, 16385, 24577, 40001])
+def test_16384_point_tiles_partitioned(ntaps, cplx):
+    """More than 8193 taps on the 16384-point kernel: partitions of 8192 taps, hop 8192 (fir_fft16k<.., LONG16>), the
+    older windows re-read and re-transformed.  Pieces that start inside the filter's reach (edge tiles with several
+    windows in the history), whole tiles, one sample; then the library's own choice on a long call agrees."""
+    rng = np.random.default_rng(ntaps + 3 * cplx)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+    P = 8192 * (1 if cplx else 2)
+    sizes = [5000, 3 * P, 1, 150000 if cplx else 300000, P - 1, 2 * P + 1]
+    x = rand(rng, sum(sizes), cplx)
+    want = O.fir(taps, x)
+    st = sdr_amd.FirState(taps, cplx, path="fft16k")
+    assert "fir_fft16k" in st.kernel_name
+    out, at = [], 0
+    for m in sizes:
+        out.append(sdr_amd.fir(st, x[at:at + m]))
+        at += m
+    assert rel_err(np.concatenate(out), want) <= TOL
+    auto = sdr_amd.FirState(taps, cplx)
+    assert "fir_fft16k" in auto.kernel_name and "short calls" in auto.kernel_name
+    assert rel_err(sdr_amd.fir(auto, x), want) <= TOL
+
+
+@pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("ntaps", [4095, 8191])
 def test_16384_point_tiles_call_sizes(ntaps, cplx):
     """fir_fft16k takes the whole call in one launch: calls of one sample, of less than a tile, of exactly one, two
@@ -182,7 +206,7 @@ def test_kernel_family_chosen_by_measured_crossover():
     # the partitioned 4096-point form for short calls; an every-other-tap design on real samples stays on the
     # complex-pair view of the 4096-point kernels
     assert "fir_fft16k" in name("bandpass", 4095, True) and "fir_fft16k" in name("bandpass", 8191, True)
-    assert "fir_fft16k<REAL>" in name("bandpass", 4095, False) and "fir_fft16k" not in name("bandpass", 8195, True)
+    assert "fir_fft16k<REAL>" in name("bandpass", 4095, False) and "fir_fft16k" in name("bandpass", 8195, True)
     assert "fir_fft16k" not in name("hilbert", 4095, False)
     assert "fir_mfma" not in name("hilbert", 61, False)      # kept taps on the odd phase
 
