@@ -1,4 +1,5 @@
-// fir_fft16k.hip -- overlap-save FIR with an in-LDS 16384-point FFT: the long-filter shape (2050..8193 taps).
+// fir_fft16k.hip -- overlap-save FIR with an in-LDS 16384-point FFT: the long-filter shape (2050..8193 taps whole,
+// partitioned at 8192 taps beyond: LONG16).
 //
 // With 4096-point tiles a filter of more than 2049 taps is partitioned (hop 2048): 4095 taps cost one forward and
 // one inverse 4096-point transform plus two spectrum products per 2048 outputs (the spectrum-cache variant of

@@ -86,7 +86,7 @@ struct FftArgs {
     // (launches on one handle are stream-ordered).  NULL: tiles are grid-strided.
     unsigned* tickets;
     int resident;         // workgroups of the single-partition kernels resident on the device at once (0: unknown)
-    // 16384-point kernel (fir_fft16k.hip; 2050..8193 taps): its spectrum (one, in that kernel's lane
+    // 16384-point kernel (fir_fft16k.hip; more than 2049 taps): its spectrum (parts16 of them beyond 8193 taps, in that kernel's lane
     // order) and twiddles; use16k: the interior of every channel runs on it in tiles of 16384 - halo16k outputs
     // (launch_fir_fft16k sets big_first / big_tiles / grid_edge / grid_carry: one launch, edge and carry workgroups included)
     const float* hperm16k;

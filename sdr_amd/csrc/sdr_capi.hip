@@ -85,7 +85,7 @@ struct sdr_fir {
     bool fft_pair = false;
     int pair_halo = 0, pair_parts = 1, pair_grid = 0, pair_resident = 0;
     float* d_hperm_pair = nullptr; // spectra of the kept taps
-    // 16384-point kernel (fir_fft16k.hip): 2050..8193 taps
+    // 16384-point kernel (fir_fft16k.hip): more than 2049 taps (partitioned at 8192 taps beyond 8193)
     int use16k = 0; // 0 no, 1 by the size of the call, 2 always (asked for by name)
     int halo16k = 0;
     float* d_hperm16k = nullptr;   // its one spectrum, then its twiddles
