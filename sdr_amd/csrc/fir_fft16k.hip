@@ -58,10 +58,10 @@
 #define SDR16K_TA_REGS 1   // W_16384 twiddles in registers (1) or re-read from the L2-resident table at each use (0)
 #endif
 #ifndef SDR16K_PF_FIRST
-#define SDR16K_PF_FIRST 8  // rows of the next tile requested right after the spectrum product;
-#endif
-#ifndef SDR16K_PF_SECOND
-#define SDR16K_PF_SECOND SDR16K_PF_FIRST // up to this row after the inverse's second stage; the rest before its block barrier
+#define SDR16K_PF_FIRST 8  // rows of the next tile requested right after the spectrum product; the rest before the inverse's block barrier
+#endif                     // (4 / 12 / 16, and a third share behind the inverse's second stage: level or slower, profiles/r03_fft16k_one_launch.txt)
+#ifndef SDR16K_PF_REAL
+#define SDR16K_PF_REAL 7
 #endif
 #ifndef SDR16K_XCD
 #define SDR16K_XCD 1       // a round of tiles dealt in contiguous runs per XCD, shared halo rows cacheable (1) or tile = blockIdx, all rows non-temporal (0)
@@ -346,9 +346,8 @@ __device__ __forceinline__ void forward16k_s(f2 (&v)[16], f2* lds, int tid, cons
 }
 
 // emit(r, value): output row r of this lane's column (x[1024 r + tid]), in the order 0 4 8 12 1 5 ...
-template <class Hook, class Emit, class HookC = NoHook>
-__device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, const Lane16k& c, Hook&& before_barrier, Emit&& emit,
-                                             HookC&& after_stage_c = HookC{}) {
+template <class Hook, class Emit>
+__device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, const Lane16k& c, Hook&& before_barrier, Emit&& emit) {
     const int l = tid & 63;
     f2* row = lds + (tid >> 6) * PK;
     const int k1 = l >> 2, k2 = l & 3, q = l >> 4, cc = l & 15;
@@ -375,7 +374,6 @@ __device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, cons
 #pragma unroll
         for (int d = 0; d < 4; ++d) row[68 * (4 * q + j) + 16 * d + cc] = w[4 * j + d];
     }
-    after_stage_c();
     wave_sync();
     // ---- B' ----
 #pragma unroll
@@ -580,6 +578,9 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         }
     };
     constexpr bool PREFETCH = SDR16K_PREFETCH && !LONG16;
+    // (real samples: seven rows early -- with eight the allocator spills three registers inside the loop, and their reloads queue
+    // behind the prefetch at HBM latency; the count is a property of this compiler's allocation, re-check it with `make asm`)
+    constexpr int PF_FIRST = REAL ? SDR16K_PF_REAL : SDR16K_PF_FIRST;
     f2 nx[16];
     if constexpr (PREFETCH) {
         const S* p = in_of(ch, t);
@@ -654,28 +655,23 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         }
         if constexpr (PREFETCH) {
 #pragma unroll
-            for (int r = 0; r < SDR16K_PF_FIRST; ++r) nx[r] = load_row(pn, r);
+            for (int r = 0; r < PF_FIRST; ++r) nx[r] = load_row(pn, r);
         }
         S* q0 = reinterpret_cast<S*>(a.out) + ch * a.out_stride + a.big_first + t * PER_TILE - HALO;
 #if SDR16K_STREAM
         inverse16k_s(w, lds, tid, c, [&] {
             if constexpr (PREFETCH) {
 #pragma unroll
-                for (int r = SDR16K_PF_SECOND; r < 16; ++r) nx[r] = load_row(pn, r);
+                for (int r = PF_FIRST; r < 16; ++r) nx[r] = load_row(pn, r);
             }
         }, [&](int r, f2 val) {
             if (r >= HROWS) store_row(q0, r, val);
-        }, [&] {
-            if constexpr (PREFETCH) {
-#pragma unroll
-                for (int r = SDR16K_PF_FIRST; r < SDR16K_PF_SECOND; ++r) nx[r] = load_row(pn, r);
-            }
         });
 #else
         inverse16k(w, lds, tid, c, [&] {
             if constexpr (PREFETCH) {
 #pragma unroll
-                for (int r = SDR16K_PF_FIRST; r < 16; ++r) nx[r] = load_row(pn, r);
+                for (int r = PF_FIRST; r < 16; ++r) nx[r] = load_row(pn, r);
             }
         });
 #pragma unroll
