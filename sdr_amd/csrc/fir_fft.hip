@@ -876,7 +876,12 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
         // (profiles/r03_fft16k_one_launch.txt: 8191 taps, 0.033 against 0.042 ms at 2^18 samples)
         const long long min_rounds = a.parts == 2 ? 2 : 1;
         const bool long_enough = a.parts > 2 && a.n * a.channels >= (1LL << 18);
-        if (a.use16k == 2 || long_enough || (rounds >= min_rounds && big * a.channels * 100 >= rounds * cus * need))
+        // many short channels are all edges -- two bounds-checked tiles per channel on a handful of workgroups: the interior
+        // must outweigh them (three to one against the cached two-partition form, one to one against the slower forms)
+        const long long edge = ((a.n + P - 1) / P - big) * a.channels;
+        const bool edges_small = edge * (a.parts == 2 ? 3 : 1) <= big * a.channels;
+        if (a.use16k == 2 ||
+            (edges_small && (long_enough || (rounds >= min_rounds && big * a.channels * 100 >= rounds * cus * need))))
             return launch_fir_fft16k(a, real, (int)cus, stream);
     }
     const long long inner = a.t_hi > a.t_lo ? a.t_hi - a.t_lo : 0;
