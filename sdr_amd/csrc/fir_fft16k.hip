@@ -418,8 +418,12 @@ __device__ __forceinline__ void inverse16k_s(f2 (&w)[16], f2* lds, int tid, cons
 
 // Edge tiles: the first tile of every channel (its window reaches back into the carried history) and the last one when
 // it is partial (outputs or inputs beyond n).  The same transform pair over the virtual stream history | input | 0,
-// bounds-checked; a few workgroups at the END of the grid take them while the interior workgroups stream.
-template <int HROWS, bool REAL, bool LONG16>
+// bounds-checked.  A few workgroups at the END of the grid start on them at once, beside the bulk: a single long stream hides
+// its two edge tiles entirely that way, sharing them out by stride.  COUNTER (calls of many channels: two edge tiles each): the
+// tiles are drawn from a counter (the handle's first ticket counter: zero between calls) and every interior workgroup that runs
+// out of tiles joins in, so that the many edge tiles spread over the chip.  (A kernel of its own -- fir_fft16k<.., HELP> --
+// because the helping epilogue costs the single-stream kernel's tile loop 6 %: profiles/r03_fft16k_one_launch.txt.)
+template <int HROWS, bool REAL, bool LONG16, bool COUNTER>
 __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base, f2* lds, const Lane16k& c, const int tid,
                                         const unsigned bid, const unsigned nblk) {
     constexpr long long HALO = 1024LL * HROWS, L = NK - HALO, PT = REAL ? 2 * L : L;
@@ -429,7 +433,16 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
     const long long total = edge_per_ch * a.channels;
     const long long t_first = a.big_first / PT;                // first interior tile
     const f2* const hbase = reinterpret_cast<const f2*>(a.hperm16k);
-    for (long long e = bid; e < total; e += nblk) {
+    __shared__ unsigned next_edge;
+    long long e = bid;
+    for (;;) {
+        if constexpr (COUNTER) {
+            __syncthreads(); // everyone has read the previous draw (and is done with the exchange buffer)
+            if (tid == 0) next_edge = atomicAdd(a.tickets, 1u);
+            __syncthreads();
+            e = next_edge;
+        }
+        if (e >= total) break;
         const long long ch = e / edge_per_ch;
         long long tt = e - ch * edge_per_ch;
         if (tt >= t_first) tt += a.big_tiles;
@@ -488,6 +501,7 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
                 *reinterpret_cast<f2*>(out + 2 * o) = val;
             }
         });
+        if constexpr (!COUNTER) e += nblk;
     }
 }
 
@@ -505,7 +519,7 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
 // spectra H_p come from L2 (a.hperm16k holds them back to back).  (parts + 1) transforms of 16384 points per 8192 outputs where
 // the 4096-point partitioned form runs (4 parts + 1) of 4096 points per 2048: 0.35-0.4 of its arithmetic.  No register prefetch
 // of the next tile in this variant: the product accumulators take its place.
-template <int HROWS, bool REAL, bool LONG16 = false>
+template <int HROWS, bool REAL, bool LONG16 = false, bool HELP = false>
 __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
     static_assert(!LONG16 || HROWS == 8, "the partitioned form hops 8192 samples");
     __shared__ __align__(16) f2 lds[16 * PK + 1024];
@@ -517,17 +531,17 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
 #endif
     constexpr long long HALO = 1024LL * HROWS, L = NK - HALO;
     const unsigned G = gridDim.x - (unsigned)a.grid_edge - (unsigned)a.grid_carry; // interior workgroups
+    Lane16k c;
     if (blockIdx.x >= G) {
         const unsigned sb = blockIdx.x - G;
         const unsigned cur = a.state->cur & 1u;
-        if (sb < (unsigned)a.grid_edge) {
-            Lane16k c;
-            c.init(tid, reinterpret_cast<const f2*>(a.wtab16k), lds + 16 * PK);
-            __syncthreads(); // the twiddle table is read by other lanes than those that filled it (the interior loop's first read follows a block barrier anyway)
-            edge16k<HROWS, REAL, LONG16>(a, pick(a.hist, cur), lds, c, tid, sb, (unsigned)a.grid_edge);
-        } else {
+        if (sb >= (unsigned)a.grid_edge) {
             carry_history<false, TK>(a, pick(a.hist, cur), pick(a.hist, cur ^ 1u), REAL ? 1 : 2, (int)(sb - (unsigned)a.grid_edge), a.grid_carry);
+            call_done();
+            return;
         }
+        c.init(tid, reinterpret_cast<const f2*>(a.wtab16k), lds + 16 * PK);
+        edge16k<HROWS, REAL, LONG16, HELP>(a, pick(a.hist, cur), lds, c, tid, sb, (unsigned)a.grid_edge);
         call_done();
         return;
     }
@@ -587,7 +601,6 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) nx[r] = load_row(p, r);
     }
-    Lane16k c;
     c.init(tid, reinterpret_cast<const f2*>(a.wtab16k), lds + 16 * PK);
     // every global access below is a wave-uniform base + this lane's 32-bit offset: one VGPR of addressing for all
     // sixteen rows (per-lane 64-bit pointers cost two registers per row, and the first build spilled exactly those)
@@ -681,6 +694,18 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
         t = tn;
         if (!more) break;
     }
+    // Help with what is left of the edge tiles.  The arguments are read again from the kernel-argument segment through a pointer
+    // the compiler cannot see through: anything this epilogue kept alive across the tile loop cost that loop registers (22 scratch
+    // operations per tile when it used the kernel's own copy of the arguments).
+    if constexpr (HELP) {
+        const char __attribute__((address_space(4)))* ka =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        FftArgs a2;
+        __builtin_memcpy(&a2, (const void*)ka, sizeof(FftArgs));
+        const unsigned cur2 = a2.state->cur & 1u;
+        edge16k<HROWS, REAL, LONG16, true>(a2, pick(a2.hist, cur2), lds, c, tid, 0u, 1u);
+    }
     call_done();
 }
 
@@ -713,14 +738,16 @@ hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t 
     const long long total = inner * a.channels, edge = (tiles_per_ch - inner) * a.channels;
     // the short work runs beside the bulk on CUs of its own: as few workgroups as finish it within the bulk's time
     // (an edge tile costs about two interior ones), at most a quarter of the chip for a call that is all edges
+    // (an edge tile costs about three interior ones; with more than a handful of edge tiles -- many channels -- what the
+    // dedicated workgroups have not taken when the bulk is through, the interior workgroups finish: fir_fft16k<.., HELP>)
     const long long bulk_rounds = total > 0 ? (total + cus - 1) / cus : 1;
-    long long ge = (2 * edge + bulk_rounds - 1) / bulk_rounds;
+    long long ge = (3 * edge + bulk_rounds - 1) / bulk_rounds;
     if (ge > edge) ge = edge;
-    if (ge > cus / 4) ge = cus / 4;
+    if (ge > cus / 8) ge = cus / 8;
     if (ge < 1) ge = 1;
     const long long hist_elems = (long long)a.hist_len * (real ? 1 : 2) * a.channels;
-    long long gc = (hist_elems + TK * 8 - 1) / (TK * 8);
-    if (gc > 8) gc = 8;
+    long long gc = (hist_elems + TK * 64 - 1) / (TK * 64);
+    if (gc > 4) gc = 4;
     if (gc < 1) gc = 1;
     long long G = cus - ge - gc;
     if (G > total) G = total;
@@ -728,15 +755,23 @@ hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t 
     a.grid_edge = (int)ge;
     a.grid_carry = (int)gc;
     const dim3 g((unsigned)(G + ge + gc)), b(TK);
+    // the helping variant when the edge tiles are more than the dedicated workgroups take in their stride within the bulk's time
+    const bool help = a.tickets != nullptr && edge > 8;
+    auto go = [&](auto hrows, auto re, auto lng) {
+        constexpr int H = decltype(hrows)::value;
+        constexpr bool R = decltype(re)::value, LG = decltype(lng)::value;
+        if (help) hipLaunchKernelGGL((fir_fft16k<H, R, LG, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((fir_fft16k<H, R, LG, false>), g, b, 0, stream, a);
+    };
     if (a.halo16k == 4096) {
-        if (real) hipLaunchKernelGGL((fir_fft16k<4, true>), g, b, 0, stream, a);
-        else hipLaunchKernelGGL((fir_fft16k<4, false>), g, b, 0, stream, a);
+        if (real) go(IC<4>{}, IC<1>{}, IC<0>{});
+        else go(IC<4>{}, IC<0>{}, IC<0>{});
     } else if (a.parts16 > 1) {
-        if (real) hipLaunchKernelGGL((fir_fft16k<8, true, true>), g, b, 0, stream, a);
-        else hipLaunchKernelGGL((fir_fft16k<8, false, true>), g, b, 0, stream, a);
+        if (real) go(IC<8>{}, IC<1>{}, IC<1>{});
+        else go(IC<8>{}, IC<0>{}, IC<1>{});
     } else {
-        if (real) hipLaunchKernelGGL((fir_fft16k<8, true>), g, b, 0, stream, a);
-        else hipLaunchKernelGGL((fir_fft16k<8, false>), g, b, 0, stream, a);
+        if (real) go(IC<8>{}, IC<1>{}, IC<0>{});
+        else go(IC<8>{}, IC<0>{}, IC<0>{});
     }
     return hipGetLastError();
 }
