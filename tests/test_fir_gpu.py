@@ -151,6 +151,19 @@ def test_16384_point_tiles_partitioned(ntaps, cplx):
     assert rel_err(sdr_amd.fir(auto, x), want) <= TOL
 
 
+@pytest.mark.parametrize("ntaps,cplx,n", [(131072, True, 300000), (131072, False, 40000), (65537, False, 600000)])
+def test_16384_point_tiles_up_to_the_longest_filter(ntaps, cplx, n):
+    """Sixteen partitions of 8192 taps (the library's limit of 131072 taps) and nine: streams shorter and longer than the filter,
+    in three calls."""
+    rng = np.random.default_rng(ntaps + n)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps)).astype(np.float32)
+    x = rand(rng, n, cplx)
+    st = sdr_amd.FirState(taps, cplx, path="fft16k")
+    cut = n // 3
+    y = np.concatenate([sdr_amd.fir(st, x[:cut]), sdr_amd.fir(st, x[cut:cut + 5]), sdr_amd.fir(st, x[cut + 5:])])
+    assert rel_err(y, O.fir(taps, x)) <= TOL
+
+
 @pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("ntaps", [4095, 8191])
 def test_16384_point_tiles_call_sizes(ntaps, cplx):
