@@ -73,3 +73,53 @@ def test_random_streams(seed):
         rms = float(np.sqrt(np.mean(np.abs(ref.astype(np.complex128)) ** 2)))
         err = float(np.max(np.abs(gc.astype(np.complex128) - ref.astype(np.complex128))))
         assert err <= TOL * rms, (seed, ntaps, cplx, C, n, bounds, st.kernel_name, c, err / rms)
+
+
+LONG_TAP_CLASSES = [(2050, 4097), (4098, 8193), (8194, 20000)]
+N_SEEDS_16K = int(os.environ.get("SDR_FUZZ_SEEDS_16K", "18"))
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS_16K))
+def test_random_streams_on_16384_point_tiles(seed):
+    """The same fuzz with the 16384-point kernel pinned (the library picks it by itself only for calls long enough to fill
+    the chip): whole filters and filters partitioned at 8192 taps, real, complex and every-other-tap designs (complex-pair
+    view), 1..3 channels with padded strides -- few interior tiles, many edge tiles, nothing written into the padding."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    lo, hi = LONG_TAP_CLASSES[seed % len(LONG_TAP_CLASSES)]
+    ntaps = int(rng.integers(lo, hi + 1))
+    cplx = bool(rng.integers(0, 2))
+    C = int(rng.integers(1, 4))
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+    if not cplx and rng.integers(0, 3) == 0 and 4100 <= ntaps <= 16385:
+        taps[1::2] = 0.0                         # (2050..8193 kept taps: the pair view runs on the 16384-point tiles too)
+    n = int(rng.integers(ntaps + 1, 160000))
+    cuts = sorted(int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 4))))
+    bounds = [0] + cuts + [n]
+    w = 2 if cplx else 1
+    x = rng.uniform(-1, 1, (C, n, w)).astype(np.float32)
+    st = sdr_amd.FirState(taps, cplx, channels=C, path="fft16k")
+    assert "fir_fft16k" in st.kernel_name
+    stream = torch.cuda.current_stream().cuda_stream
+    pad = 2 * int(rng.integers(0, 5))
+    got = np.empty_like(x)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        m = b - a
+        if m == 0:
+            continue
+        stride = m + pad
+        d_in = torch.zeros((C, stride, w), dtype=torch.float32, device="cuda")
+        d_in[:, :m] = torch.from_numpy(x[:, a:b])
+        d_out = torch.full((C, stride, w), 777.0, dtype=torch.float32, device="cuda")
+        st.process_device(d_in.data_ptr(), m, d_out.data_ptr(), in_stride=stride, out_stride=stride, stream=stream)
+        torch.cuda.synchronize()
+        o = d_out.cpu().numpy()
+        assert np.all(o[:, m:] == 777.0)
+        got[:, a:b] = o[:, :m]
+    for c in range(C):
+        xc = x[c].reshape(-1).view(np.complex64) if cplx else x[c].reshape(-1)
+        gc = got[c].reshape(-1).view(np.complex64) if cplx else got[c].reshape(-1)
+        ref = O.fir(taps, xc)
+        rms = float(np.sqrt(np.mean(np.abs(ref.astype(np.complex128)) ** 2)))
+        err = float(np.max(np.abs(gc.astype(np.complex128) - ref.astype(np.complex128))))
+        assert err <= TOL * rms, (seed, ntaps, cplx, C, n, bounds, st.kernel_name, c, err / rms)
