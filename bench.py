@@ -33,6 +33,7 @@ import argparse
 import json
 import os
 import socket
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -350,8 +351,8 @@ def collect_traffic(workload, path):
         d = tempfile.mkdtemp(dir="/tmp", prefix="sdr_pmc_")
         cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--workload", workload, "--path", path, "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline"]
-        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
+               "--no-cpu-baseline", "--no-pmc"]
+        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True,
                        env=dict(os.environ, TMPDIR="/tmp"))
         per = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -454,7 +455,10 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "direct", "fft", "mfma", "fft4k", "fft16k"],
                     help="experiments: pin the kernel family (the default is the library's own choice)")
     ap.add_argument("--pmc", action="store_true",
-                    help="collect roofline.traffic live: two extra rocprofv3 --pmc passes of a short run (N=1 only)")
+                    help="collect roofline.traffic live: two extra rocprofv3 --pmc passes of a short run (N=1 only).  The full "
+                         "default run (one GPU, CPU baseline included, not itself under a profiler) does so by itself and falls "
+                         "back to the committed profiles/traffic_<workload>.json if the passes fail")
+    ap.add_argument("--no-pmc", action="store_true", help="never start the rocprofv3 passes")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -666,12 +670,19 @@ def run_and_report(args, torch, dist, rank, world, dev, wl):
                                      "(sharding.GatherPlan: sizes from the plan, no allocation per step); p2p = every rank sends "
                                      "straight into its place (batch_isend_irecv), gather = the rooted collective"}
         tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if args.pmc and world == 1:
-            live = collect_traffic(args.workload, args.path)
-            if live:
-                out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, "
-                                                     "separate passes of this command")
+        profiled = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        want_live = world == 1 and not args.no_pmc and (args.pmc or (not args.no_cpu_baseline and not profiled and
+                                                                     args.workload != "c1pipe" and shutil.which("rocprofv3")))
+        live = None
+        if want_live:
+            try:
+                live = collect_traffic(args.workload, args.path)
+            except Exception as e:  # a failed or timed-out pass must not cost the bench line
+                sys.stderr.write("bench.py: live traffic collection failed (%s); using the committed file\n" % (e,))
+        if live:
+            out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE, two separate "
+                                                 "passes of a short run of this command after the timed region")
         elif os.path.exists(tj) and args.path == "auto" and world == 1:
             with open(tj) as f:
                 rec = json.load(f)
