@@ -352,7 +352,7 @@ def collect_traffic(workload, path):
         cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--workload", workload, "--path", path, "--steps", "3", "--warmup", "1",
                "--no-cpu-baseline", "--no-pmc"]
-        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True,
+        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60, check=True,
                        env=dict(os.environ, TMPDIR="/tmp"))
         per = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
