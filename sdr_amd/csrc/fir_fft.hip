@@ -864,22 +864,22 @@ hipError_t launch_fir_fft(const FftArgs& a0, bool real, int grid_blocks, hipStre
     // own) when the call fills the chip with them: worth it when the last round of one-tile-per-CU workgroups is full
     // enough -- per sample the big tile costs 0.84 of the cached two-partition form and about half of the three- and
     // four-partition forms (use16k == 2: the caller asked for this path by name, every call takes it)
-    if (a.use16k && !a.gen.enabled && a.parts >= 2 && a.hperm16k) { // (halo16k / parts16 cover the taps: sdr_capi.hip)
+    if (a.use16k && !a.gen.enabled && (a.parts >= 2 || a.halo == 2048) && a.hperm16k) { // (halo16k / parts16 cover the taps: sdr_capi.hip)
         long long P, first, big;
         fir_fft16k_tiles(a.n, a.halo16k, real, a.parts16 > 1 ? a.parts16 : 1, &P, &first, &big);
         const long long cus = a.cus16k > 0 ? a.cus16k : 256;
         const long long rounds = (big * a.channels + cus - 1) / cus;
-        const long long need = a.parts == 2 ? 84 : 50;
+        const long long need = a.parts <= 2 ? 84 : 50;
         // (its edge tiles run beside the bulk but cost ~40 us whatever the size: against the cached two-partition form
         // it takes two rounds of tiles to be ahead, profiles/r03_fft16k_one_launch.txt)
         // the three- and four-partition forms lose from 2^18 samples per call on, whatever the fill
         // (profiles/r03_fft16k_one_launch.txt: 8191 taps, 0.033 against 0.042 ms at 2^18 samples)
-        const long long min_rounds = a.parts == 2 ? 2 : 1;
+        const long long min_rounds = a.parts <= 2 ? 2 : 1;
         const bool long_enough = a.parts > 2 && a.n * a.channels >= (1LL << 18);
         // many short channels are all edges -- two bounds-checked tiles per channel on a handful of workgroups: the interior
         // must outweigh them (three to one against the cached two-partition form, one to one against the slower forms)
         const long long edge = ((a.n + P - 1) / P - big) * a.channels;
-        const bool edges_small = edge * (a.parts == 2 ? 3 : 1) <= big * a.channels;
+        const bool edges_small = edge * (a.parts <= 2 ? 3 : 1) <= big * a.channels;
         if (a.use16k == 2 ||
             (edges_small && (long_enough || (rounds >= min_rounds && big * a.channels * 100 >= rounds * cus * need))))
             return launch_fir_fft16k(a, real, (int)cus, stream);

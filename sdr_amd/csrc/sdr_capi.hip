@@ -413,9 +413,9 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // kernel with the spectrum of the kept taps (up to 8193 kept taps: a 16385-tap Hilbert design)
     const bool want16k = use_fft && path != SDR_PATH_FFT4K && (path == SDR_PATH_FFT16K || SDR_FFT16K_AUTO);
     // (beyond 8193 taps: 16384-point tiles partitioned at 8192 taps, up to 16 partitions = 131072 taps)
-    const bool main16k = want16k && fft_parts >= 2;
+    const bool main16k = want16k && (fft_parts >= 2 || fft_halo == 2048);   // from 1026 taps on
     const int parts16 = ntaps - 1 <= 8192 ? 1 : (int)((ntaps + 8191) / 8192);
-    const bool pair16k = want16k && f->fft_pair && f->pair_parts >= 2 && f->pair_parts <= 4;
+    const bool pair16k = want16k && f->fft_pair && ((f->pair_parts >= 2 && f->pair_parts <= 4) || (f->pair_parts == 1 && f->pair_halo == 2048));
     if (main16k || pair16k) {
         const int NK = 16384;
         std::vector<double> cs(NK), sn(NK);
@@ -448,13 +448,13 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         if (main16k) {
             if ((e = upload(taps, ntaps, parts16, true, &f->d_hperm16k)) != hipSuccess) return bail(e, "16384-point spectrum");
             f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK * parts16;
-            f->halo16k = ntaps - 1 <= 4096 ? 4096 : 8192;
+            f->halo16k = ntaps - 1 <= 2048 ? 2048 : ntaps - 1 <= 4096 ? 4096 : 8192;
             f->parts16 = parts16;
         }
         if (pair16k) {
             if ((e = upload(g.data(), plan.kept, 1, !main16k, &f->d_hperm16k_pair)) != hipSuccess) return bail(e, "16384-point spectrum");
             if (!main16k) f->d_wtab16k = f->d_hperm16k_pair + (size_t)2 * NK;
-            f->pair_halo16k = plan.kept - 1 <= 4096 ? 4096 : 8192;
+            f->pair_halo16k = plan.kept - 1 <= 2048 ? 2048 : plan.kept - 1 <= 4096 ? 4096 : 8192;
         }
         f->use16k = path == SDR_PATH_FFT16K ? 2 : 1;
     }

@@ -98,7 +98,7 @@ def test_matrix_core_kernels(kind, ntaps, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
-@pytest.mark.parametrize("ntaps", [2050, 4095, 4097, 4098, 6143, 8191, 8192])
+@pytest.mark.parametrize("ntaps", [1026, 1537, 2049, 2050, 4095, 4097, 4098, 6143, 8191, 8192])
 def test_16384_point_tiles_for_long_filters(ntaps, cplx):
     """fir_fft16k (one 16384-point tile holds a filter of 2050..8193 taps: halo 4096 or 8192, one spectrum, no
     partitions; fir_fft16k.hip) pinned through the internal hook, complex samples and real ones (two stretches of the
@@ -165,14 +165,14 @@ def test_16384_point_tiles_up_to_the_longest_filter(ntaps, cplx, n):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
-@pytest.mark.parametrize("ntaps", [4095, 8191])
+@pytest.mark.parametrize("ntaps", [2049, 4095, 8191])
 def test_16384_point_tiles_call_sizes(ntaps, cplx):
     """fir_fft16k takes the whole call in one launch: calls of one sample, of less than a tile, of exactly one, two
     and three tiles' worth of outputs, and one sample either side of those (the last tile is an edge tile exactly when
     it is partial), as consecutive pieces of one stream."""
     rng = np.random.default_rng(ntaps + cplx)
     taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
-    P = (16384 - (4096 if ntaps - 1 <= 4096 else 8192)) * (1 if cplx else 2)
+    P = (16384 - (2048 if ntaps - 1 <= 2048 else 4096 if ntaps - 1 <= 4096 else 8192)) * (1 if cplx else 2)
     sizes = [1, 100, P - 1, P, P + 1, 2 * P, 2 * P - 1, 3 * P, 3 * P + 1, 7]
     x = rand(rng, sum(sizes), cplx)
     st = sdr_amd.FirState(taps, cplx, path="fft16k")
@@ -214,13 +214,15 @@ def test_kernel_family_chosen_by_measured_crossover():
     assert "fir_mfma" in name("lowpass", 31, True) and "fir_mfma" in name("lowpass", 49, False)
     assert "fir_mfma" in name("hilbert", 63, False) and "fir_mfma" in name("hilbert", 95, True)
     assert "fir_fft4096" in name("lowpass", 65, True) and "fir_fft4096" in name("hilbert", 127, False)
-    assert "fir_fft4096" in name("lowpass", 127, True) and "fir_fft4096" in name("bandpass", 2049, True)
+    assert "fir_fft4096" in name("lowpass", 127, True) and "fir_fft16k" not in name("bandpass", 1025, True)
+    assert "fir_fft16k" in name("bandpass", 1026, True) and "fir_fft16k" in name("bandpass", 2049, False)   # halo 2048: from 1026 taps on
     # 2050..8192 taps: 16384-point tiles when the call fills the chip with them (profiles/r03_long_taps_16k.txt),
-    # the partitioned 4096-point form for short calls; an every-other-tap design on real samples stays on the
-    # complex-pair view of the 4096-point kernels
+    # the 4096-point forms for short calls; an every-other-tap design on real samples takes them on its complex-pair
+    # view when it keeps 1026 taps or more
     assert "fir_fft16k" in name("bandpass", 4095, True) and "fir_fft16k" in name("bandpass", 8191, True)
     assert "fir_fft16k<REAL>" in name("bandpass", 4095, False) and "fir_fft16k" in name("bandpass", 8195, True)
-    assert "fir_fft16k" not in name("hilbert", 4095, False)
+    assert "fir_fft16k<REAL as complex pairs>" in name("hilbert", 4095, False)    # 2048 kept taps: halo 2048 on the pair view
+    assert "fir_fft16k" not in name("hilbert", 2047, False)                       # 1024 kept taps: 4096-point tiles
     assert "fir_mfma" not in name("hilbert", 61, False)      # kept taps on the odd phase
 
 

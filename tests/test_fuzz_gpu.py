@@ -75,8 +75,8 @@ def test_random_streams(seed):
         assert err <= TOL * rms, (seed, ntaps, cplx, C, n, bounds, st.kernel_name, c, err / rms)
 
 
-LONG_TAP_CLASSES = [(2050, 4097), (4098, 8193), (8194, 20000)]
-N_SEEDS_16K = int(os.environ.get("SDR_FUZZ_SEEDS_16K", "18"))
+LONG_TAP_CLASSES = [(1026, 2049), (2050, 4097), (4098, 8193), (8194, 20000)]
+N_SEEDS_16K = int(os.environ.get("SDR_FUZZ_SEEDS_16K", "20"))
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS_16K))
@@ -91,8 +91,8 @@ def test_random_streams_on_16384_point_tiles(seed):
     cplx = bool(rng.integers(0, 2))
     C = int(rng.integers(1, 4))
     taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
-    if not cplx and rng.integers(0, 3) == 0 and 4100 <= ntaps <= 16385:
-        taps[1::2] = 0.0                         # (2050..8193 kept taps: the pair view runs on the 16384-point tiles too)
+    if not cplx and rng.integers(0, 3) == 0 and 2052 <= ntaps <= 16385:
+        taps[1::2] = 0.0                         # (1026..8193 kept taps: the pair view runs on the 16384-point tiles too)
     n = int(rng.integers(ntaps + 1, 160000))
     cuts = sorted(int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 4))))
     bounds = [0] + cuts + [n]
