@@ -359,6 +359,7 @@ def collect_traffic(workload, path):
             for row in csv.DictReader(open(f)):
                 if row["Counter_Name"] == counter and "fir_" in row["Kernel_Name"]:
                     per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
         if not per:
             return None
         name = max(per, key=lambda k: sum(per[k]))
