@@ -1,5 +1,5 @@
-// fir_fft16k.hip -- overlap-save FIR with an in-LDS 16384-point FFT: the long-filter shape (1026..8193 taps whole -- halo 2048, 4096
-// or 8192 --, partitioned at 8192 taps beyond: LONG16).  From 1026 taps on a 4096-point tile is half halo (0.42 of HBM peak at 2049 taps).
+// fir_fft16k.hip -- overlap-save FIR with an in-LDS 16384-point FFT: the long-filter shape (1026..8193 taps whole -- halo 2048 .. 8192
+// in rows of 1024 --, partitioned at 8192 taps beyond: LONG16).  From 1026 taps on a 4096-point tile is half halo (0.42 of HBM peak at 2049 taps).
 //
 // With 4096-point tiles a filter of more than 2049 taps is partitioned (hop 2048): 4095 taps cost one forward and
 // one inverse 4096-point transform plus two spectrum products per 2048 outputs (the spectrum-cache variant of
@@ -505,7 +505,7 @@ __device__ __forceinline__ void edge16k(const FftArgs& a, const float* hist_base
     }
 }
 
-// HROWS = halo / 1024 (2, 4 or 8).  One launch per call.  Tiles of a channel: tile t produces outputs [t P, t P + P),
+// HROWS = halo / 1024 (2 .. 8: the smallest number of rows that holds the taps).  One launch per call.  Tiles of a channel: tile t produces outputs [t P, t P + P),
 // P = L = 16384 - halo (REAL: 2 L), reading 16384 inputs from t P - halo.  Interior tiles -- every input and output
 // inside [0, n): tiles 1 .. a.big_tiles, tile t' = t - 1 starting at a.big_first + t' P with a.big_first = P -- are
 // walked by the first G workgroups of the grid, persistently; behind them come a.grid_edge workgroups for the edge
@@ -726,7 +726,7 @@ void fir_fft16k_tiles(long long n, int halo16k, bool real, int parts16, long lon
 // The whole call in one launch: interior, edge and carry workgroups (see fir_fft16k); `cus` = CUs of the device.
 hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t stream) {
     if (a0.n <= 0 || a0.channels <= 0) return hipSuccess;
-    if (!a0.hperm16k || !a0.wtab16k || !a0.state || (a0.halo16k != 2048 && a0.halo16k != 4096 && a0.halo16k != 8192)) return hipErrorInvalidValue;
+    if (!a0.hperm16k || !a0.wtab16k || !a0.state || a0.halo16k < 2048 || a0.halo16k > 8192 || a0.halo16k % 1024 != 0) return hipErrorInvalidValue;
     if (a0.parts16 > 1 && a0.halo16k != 8192) return hipErrorInvalidValue;
     FftArgs a = a0;
     long long P, t_first, inner;
@@ -763,18 +763,23 @@ hipError_t launch_fir_fft16k(const FftArgs& a0, bool real, int cus, hipStream_t 
         if (help) hipLaunchKernelGGL((fir_fft16k<H, R, LG, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((fir_fft16k<H, R, LG, false>), g, b, 0, stream, a);
     };
-    if (a.halo16k == 2048) {
-        if (real) go(IC<2>{}, IC<1>{}, IC<0>{});
-        else go(IC<2>{}, IC<0>{}, IC<0>{});
-    } else if (a.halo16k == 4096) {
-        if (real) go(IC<4>{}, IC<1>{}, IC<0>{});
-        else go(IC<4>{}, IC<0>{}, IC<0>{});
-    } else if (a.parts16 > 1) {
+    auto whole = [&](auto hrows) {
+        if (real) go(hrows, IC<1>{}, IC<0>{});
+        else go(hrows, IC<0>{}, IC<0>{});
+    };
+    if (a.parts16 > 1) {
         if (real) go(IC<8>{}, IC<1>{}, IC<1>{});
         else go(IC<8>{}, IC<0>{}, IC<1>{});
     } else {
-        if (real) go(IC<8>{}, IC<1>{}, IC<0>{});
-        else go(IC<8>{}, IC<0>{}, IC<0>{});
+        switch (a.halo16k / 1024) { // the halo in whole rows of 1024 samples: the smallest that holds the taps
+            case 2: whole(IC<2>{}); break;
+            case 3: whole(IC<3>{}); break;
+            case 4: whole(IC<4>{}); break;
+            case 5: whole(IC<5>{}); break;
+            case 6: whole(IC<6>{}); break;
+            case 7: whole(IC<7>{}); break;
+            default: whole(IC<8>{}); break;
+        }
     }
     return hipGetLastError();
 }

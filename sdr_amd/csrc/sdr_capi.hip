@@ -448,13 +448,13 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
         if (main16k) {
             if ((e = upload(taps, ntaps, parts16, true, &f->d_hperm16k)) != hipSuccess) return bail(e, "16384-point spectrum");
             f->d_wtab16k = f->d_hperm16k + (size_t)2 * NK * parts16;
-            f->halo16k = ntaps - 1 <= 2048 ? 2048 : ntaps - 1 <= 4096 ? 4096 : 8192;
+            f->halo16k = parts16 > 1 ? 8192 : std::max(2048, 1024 * (int)((ntaps - 1 + 1023) / 1024)); // whole rows of 1024 samples
             f->parts16 = parts16;
         }
         if (pair16k) {
             if ((e = upload(g.data(), plan.kept, 1, !main16k, &f->d_hperm16k_pair)) != hipSuccess) return bail(e, "16384-point spectrum");
             if (!main16k) f->d_wtab16k = f->d_hperm16k_pair + (size_t)2 * NK;
-            f->pair_halo16k = plan.kept - 1 <= 2048 ? 2048 : plan.kept - 1 <= 4096 ? 4096 : 8192;
+            f->pair_halo16k = std::max(2048, 1024 * (int)((plan.kept - 1 + 1023) / 1024));
         }
         f->use16k = path == SDR_PATH_FFT16K ? 2 : 1;
     }
