@@ -110,10 +110,12 @@ def kernel_flops_per_sample(kernel_name, ntaps, cplx, nonzero_taps, gen=False):
         # 16384-point tiles (fir_fft16k.hip): per lane and transform, three 16-point butterflies (176 flops), one
         # stage of four 4-point ones (64) and 42 twiddle products (6 each): 844; 1024 lanes, two transforms and
         # sixteen spectrum products per lane per tile of 16384 - halo outputs
-        return (2 * 844 * 1024 + 16 * 6 * 1024) / (16384.0 - (4096 if ntaps <= 4097 else 8192))
-    halo = 64
-    while halo + 1 < ntaps and halo < 2048:
-        halo *= 2
+        # (halo in whole rows of 1024 samples, two to eight; partitioned at 8192 taps beyond: one more forward transform
+        # and product per further partition)
+        parts = max(1, -(-ntaps // 8192)) if ntaps > 8193 else 1
+        halo = 8192 if parts > 1 else max(2048, 1024 * -(-(ntaps - 1) // 1024))
+        return ((parts + 1) * 844 * 1024 + parts * 16 * 6 * 1024 + (parts - 1) * 16 * 2 * 1024) / (16384.0 - halo)
+    halo = next((h for h in (64, 128, 192, 256, 384, 512, 768, 1024) if ntaps <= h + 1), 2048)   # fir_fft_plan
     if ntaps <= 2049:
         per_tile = (4096 - halo) * (1 if cplx else 2)   # real signals ride in pairs
         return FFT_TILE_FLOPS / per_tile + (20.0 if gen else 0.0)

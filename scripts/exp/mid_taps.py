@@ -5,7 +5,7 @@ n = 1 << 27
 x = torch.rand((n, 2), dtype=torch.float32, device="cuda") * 2 - 1
 y = torch.empty_like(x)
 stream = torch.cuda.current_stream().cuda_stream
-for ntaps in (1025, 2049, 2050, 3001, 4095, 4098, 5000, 6143, 7000, 8191):
+for ntaps in [int(a) for a in sys.argv[1:]] or (1025, 2049, 2050, 3001, 4095, 4098, 5000, 6143, 7000, 8191):
     taps = sdr_amd.fir_lowpass(ntaps, 0.1)
     st = sdr_amd.FirState(taps, True)
     for _ in range(30):

@@ -338,7 +338,7 @@ __device__ __forceinline__ void interior_tiles(const FftArgs& a0, f2* lds, LaneC
     if constexpr (GEN == 0 && REAL) asm volatile("" : "+s"(al.in_stride), "+s"(al.channels)); // (the two it re-loads there)
     const FftArgs& a = (GEN != 0 || REAL) ? al : a0;
     static_assert(!LONG || HQ == 32, "partitioned mode uses hop 2048");
-    static_assert(HQ >= 1 && HQ <= 32 && (HQ & (HQ - 1)) == 0, "halo = 64 * {1,2,4,8,16,32}");
+    static_assert(HQ >= 1 && HQ <= 32, "halo = 64 * HQ, at most half a tile");
     static_assert(!CACHE || LONG, "the spectrum cache belongs to the partitioned mode");
     static_assert(!GEN || REAL, "the generator source produces real samples");
     const int tid = threadIdx.x;
@@ -828,8 +828,11 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
     switch (a.halo / 64) {
         case 1: hipLaunchKernelGGL((fir_fft4096<REAL, 1, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         case 2: hipLaunchKernelGGL((fir_fft4096<REAL, 2, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((fir_fft4096<REAL, 3, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         case 4: hipLaunchKernelGGL((fir_fft4096<REAL, 4, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL((fir_fft4096<REAL, 6, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         case 8: hipLaunchKernelGGL((fir_fft4096<REAL, 8, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
+        case 12: hipLaunchKernelGGL((fir_fft4096<REAL, 12, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         case 16: hipLaunchKernelGGL((fir_fft4096<REAL, 16, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         case 32: hipLaunchKernelGGL((fir_fft4096<REAL, 32, false, TBLK, false, GEN>), g, b, 0, stream, a); break;
         default: return hipErrorInvalidValue;
@@ -837,12 +840,13 @@ static hipError_t launch_tiles(const FftArgs& a, long long grid_int, hipStream_t
     return hipGetLastError();
 }
 
-// Tiling for a tap count: halo = 64 * {1,2,4,8,16,32} old samples per tile for up to 2049
-// taps (one spectrum; 127 taps -> 128, i.e. 3968 new samples per 4096-point tile); beyond
-// that hop 2048 with ceil(ntaps/2048) partitions.
+// Tiling for a tap count: halo = 64 * {1,2,3,4,6,8,12,16,32} old samples per tile for up to 2049
+// taps (one spectrum; 127 taps -> 128, i.e. 3968 new samples per 4096-point tile; a tile costs the
+// same whatever its halo, so the classes in between -- 192, 384, 768 -- are worth their kernels:
+// 700 taps 3328 instead of 3072 new samples per tile); beyond that hop 2048 with ceil(ntaps/2048) partitions.
 void fir_fft_plan(size_t ntaps, int* halo, int* parts) {
     *parts = 1;
-    for (int hq : {1, 2, 4, 8, 16, 32})
+    for (int hq : {1, 2, 3, 4, 6, 8, 12, 16, 32})
         if (ntaps <= (size_t)64 * hq + 1) { *halo = 64 * hq; return; }
     *halo = 2048;
     *parts = (int)((ntaps + 2047) / 2048);

@@ -98,10 +98,40 @@ def test_matrix_core_kernels(kind, ntaps, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("ntaps", [130, 193, 194, 300, 385, 386, 700, 769, 770])
+def test_4096_point_tiles_halo_classes_in_between(ntaps, cplx):
+    """Halos of 192, 384 and 768 samples (fir_fft.hip: fir_fft_plan) between the power-of-two classes, at their first
+    and last tap counts and one past (the next class): a stream of many tiles cut at tile-sized, tiny and ragged
+    places, then the same filter on three channels with a padded stride, and on a Hilbert-shaped design through
+    the pair view (kept taps decide the class there)."""
+    rng = np.random.default_rng(ntaps + 7 * cplx)
+    taps = (rng.uniform(-1, 1, ntaps) * np.hanning(ntaps + 2)[1:-1]).astype(np.float32)
+    n = 150001
+    x = rand(rng, n, cplx)
+    st = sdr_amd.FirState(taps, cplx, path="fft")
+    assert "fir_fft4096" in st.kernel_name, st.kernel_name
+    cuts = [0, 1, 4000, 4001, 12288, 70000, n]
+    y = np.concatenate([sdr_amd.fir(st, x[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)])
+    assert rel_err(y, O.fir(taps, x)) <= TOL
+    C, m = 3, 40001
+    x2 = np.stack([rand(rng, m, cplx) for _ in range(C)])
+    st2 = sdr_amd.FirState(taps, cplx, channels=C, path="fft")
+    y2 = np.concatenate([sdr_amd.fir(st2, x2[:, :9000]), sdr_amd.fir(st2, x2[:, 9000:])], axis=1)
+    for c in range(C):
+        assert rel_err(y2[c], O.fir(taps, x2[c])) <= TOL, c
+    if not cplx:
+        h = sdr_amd.hilbert(2 * ntaps - 1)      # ntaps kept taps
+        st3 = sdr_amd.FirState(h, False, path="fft")
+        xr = rand(rng, n, False)
+        y3 = np.concatenate([sdr_amd.fir(st3, xr[:50001]), sdr_amd.fir(st3, xr[50001:])])
+        assert rel_err(y3, O.fir(h, xr)) <= TOL, st3.kernel_name
+
+
+@pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("ntaps", [1026, 1537, 2049, 2050, 4095, 4097, 4098, 6143, 8191, 8192])
 def test_16384_point_tiles_for_long_filters(ntaps, cplx):
-    """fir_fft16k (one 16384-point tile holds a filter of 2050..8193 taps: halo 4096 or 8192, one spectrum, no
-    partitions; fir_fft16k.hip) pinned through the internal hook, complex samples and real ones (two stretches of the
+    """fir_fft16k (one 16384-point tile holds a filter of 1026..8193 taps: a halo of two to eight rows of 1024 samples,
+    one spectrum, no partitions; fir_fft16k.hip) pinned through the internal hook, complex samples and real ones (two stretches of the
     stream as re / im of one transform): a stream long enough for many big tiles, cut so that calls start and end
     inside, at and between tile boundaries (the 2048-sample tiles at both ends of a call go to the 4096-point
     partitioned form), then three channels with a padded stride; and the same stream through the 4096-point kernels
