@@ -116,6 +116,46 @@ def test_random_generated_chains(seed):
     got = out[:done].cpu().numpy()
     rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
     err = float(np.max(np.abs(got.astype(np.float64) - ref)))
-    # a tone in a stop band leaves an output far below the signal: the bar is against the
-    # signal's RMS (the generator's amplitude) when the output's own RMS is smaller
-    assert err <= TOL * max(rms, amp / np.sqrt(2.0) * 0.05), (seed, wf, amp, phase, cps, B, nt1, nt2, calls, err / rms)
+    assert err <= TOL * max(rms, null_floor(stages, amp)), (seed, wf, amp, phase, cps, B, nt1, nt2, calls, err / rms)
+
+
+def null_floor(stages, amp):
+    """A tone in a stop band (or in the null of one stage of the chain) leaves an output far below what the fused
+    filter makes of a signal of that level -- the signal's RMS times the l2 norm of the fused taps, its gain for white
+    input and therefore for the fp32 rounding noise of any evaluation of it.  Where the expected output is below a tenth
+    of that level the bar is held against the tenth.  (Seed 120 of a 600-seed soak: a near-DC cosine through a Hilbert
+    stage, whose null it sits in, then 255 random taps of l2 norm 5.6; output 0.042 of that level.  The reference's own
+    arithmetic -- fp32 kfr::fir, one stage after the other -- is 7.8e-6 of the output RMS away from the double-precision
+    oracle there, the fused path 1.5e-5: tests/chain_conditioning.py, profiles/r03_chain_conditioning.txt.)"""
+    h = np.array([1.0])
+    for taps, _ in stages:
+        h = np.convolve(h, np.asarray(taps, np.float64))
+    return 0.1 * amp / np.sqrt(2.0) * max(1.0, float(np.sqrt(np.sum(h * h))))
+
+
+def test_tone_in_the_null_of_a_stage():
+    """The shape of seed 120 above as a fixed case: cosine of amplitude 2.2 at -0.000609 cycles per sample, packets of
+    1000 samples, Hilbert 127 (skip 63) then 255 random windowed taps (skip 12); 19 packets in calls of 1, 17 and 1."""
+    import torch
+    rng = np.random.default_rng(8120)
+    amp, cps, B = 2.2010433673858643, -0.0006090959650464356, 1000
+    t2 = (rng.uniform(-1, 1, 255) * np.hanning(257)[1:-1]).astype(np.float32)
+    stages = [(sdr_amd.hilbert(127), 63), (t2, 12)]
+    gen = sdr_amd.Gen("cosine", False, amp, cps, 45.0, B)
+    chain = sdr_amd.Chain(stages, False)
+    calls, total = [1, 17, 1], 19
+    out = torch.full((total * B,), 777.0, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    done = 0
+    for nb in calls:
+        done += chain.generate_device(gen, nb, out.data_ptr() + 4 * done, stream=stream)
+    torch.cuda.synchronize()
+    assert done == total * B - 75
+    x, _ = O.gen_real(total, B, amp, cps, 0.125, sdr_amd.WAVEFORMS["cosine"])
+    ref = staged_oracle(stages, x)
+    rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    err = float(np.max(np.abs(out[:done].cpu().numpy().astype(np.float64) - ref)))
+    floor = null_floor(stages, amp)
+    print("tone in a null: err %.3e = %.3e of the output RMS (%.4f), %.3e of the level the bar is held against (%.4f)" % (err, err / rms, rms, err / floor, floor))
+    assert rms < floor                    # the case is what it says: the output is below a tenth of the filter's level
+    assert err <= TOL * floor
