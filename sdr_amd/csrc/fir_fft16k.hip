@@ -4,9 +4,10 @@
 // With 4096-point tiles a filter of more than 2049 taps is partitioned (hop 2048): 4095 taps cost one forward and
 // one inverse 4096-point transform plus two spectrum products per 2048 outputs (the spectrum-cache variant of
 // fir_fft.hip), 8191 taps four forward transforms and one inverse.  One 16384-point tile holds the whole filter:
-// halo 4096 (up to 4097 taps: 12288 new outputs per tile) or 8192 (up to 8193 taps: 8192 outputs), ONE spectrum, no
-// partitions -- 0.99 vector instructions per output at 4095 taps where the cached 4096-point form executes 1.52,
-// and a quarter of what the partitioned form executes at 8191.
+// a halo of two to eight rows of 1024 samples, the fewest that hold the taps (four rows up to 4097 taps: 12288 new
+// outputs per tile; eight up to 8193 taps: 8192 outputs), ONE spectrum, no partitions -- 0.99 vector instructions
+// per output at 4095 taps where the cached 4096-point form executes 1.52, and a quarter of what the partitioned
+// form executes at 8191.
 //
 // One workgroup of 1024 lanes (16 waves, four per SIMD) owns the CU: the tile fills the LDS (16 rows of 1088
 // complex = 136 KB, + an 8 KB twiddle table).  Each lane keeps 16 complex points; radix 16 . 16 . 4 . 16:
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(1024, 4) void fir_fft16k(FftArgs a) {
     // (channel, tile) of this workgroup's current and next tile, advanced without a division: the flat list is walked
     // grid-strided, and stride = dq big_tiles + dr is split once
     const int tiles = (int)a.big_tiles, channels = a.channels;
-    // Neighbouring tiles share a halo of 4096 or 8192 samples (a third or all of what a tile reads).  Workgroups go
+    // Neighbouring tiles share a halo of 2048 .. 8192 samples (a seventh to all of what a tile reads).  Workgroups go
     // to the eight XCDs round-robin by blockIdx, each XCD with an L2 of its own: with tile = blockIdx every halo was
     // fetched through two L2s -- 1.36x the algorithmic reads at 4095 taps, 1.07x now (profiles/r03_c3_summary.txt).
     // A round of the grid is dealt in eight contiguous runs instead, one per XCD (XCD x holds the workgroups
