@@ -114,7 +114,8 @@ def kernel_flops_per_sample(kernel_name, ntaps, cplx, nonzero_taps, gen=False):
         # and product per further partition)
         parts = max(1, -(-ntaps // 8192)) if ntaps > 8193 else 1
         halo = 8192 if parts > 1 else max(2048, 1024 * -(-(ntaps - 1) // 1024))
-        return ((parts + 1) * 844 * 1024 + parts * 16 * 6 * 1024 + (parts - 1) * 16 * 2 * 1024) / (16384.0 - halo)
+        per_tile = (16384.0 - halo) * (1 if cplx else 2)   # real signals ride in pairs
+        return ((parts + 1) * 844 * 1024 + parts * 16 * 6 * 1024 + (parts - 1) * 16 * 2 * 1024) / per_tile
     halo = next((h for h in (64, 128, 192, 256, 384, 512, 768, 1024) if ntaps <= h + 1), 2048)   # fir_fft_plan
     if ntaps <= 2049:
         per_tile = (4096 - halo) * (1 if cplx else 2)   # real signals ride in pairs
