@@ -280,7 +280,11 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // 5.4-6.0 TB/s (0.67-0.75 of HBM peak) where the direct form has turned VALU-bound and the
     // overlap-save kernel sits at 5.1-5.3; below, the direct form is level or ahead; from 50 kept
     // taps up the fp32 matrix pipe is the bottleneck and the overlap-save kernel is faster.
-    const bool mfma_auto = (path == SDR_PATH_AUTO || path == SDR_PATH_DIRECT_FORMS) && mfma_smax != 0 && plan.kept >= 17 && plan.kept <= 49;
+    // (Round 3: the overlap-save kernel gained 1.4-3.7 % from its third ticket counter, and for dense filters the
+    // crossover moved down with it -- level at 41 kept taps, overlap-save ahead by 0.6 % at 45 and 1.2-2 % at 49,
+    // complex and real: profiles/r03_mfma_vs_fft.txt.  Every-other-tap designs stay level up to 49 kept taps.)
+    const size_t mfma_last = stride == 2 ? 49 : 44;
+    const bool mfma_auto = (path == SDR_PATH_AUTO || path == SDR_PATH_DIRECT_FORMS) && mfma_smax != 0 && plan.kept >= 17 && plan.kept <= mfma_last;
     if (mfma_auto) f->use_fft = use_fft = false;
     const bool use_mfma = mfma_auto || (!use_fft && path == SDR_PATH_MFMA);
     if (use_mfma && mfma_smax == 0) {
