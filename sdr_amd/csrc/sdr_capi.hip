@@ -283,8 +283,13 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     // (Round 3: the overlap-save kernel gained 1.4-3.7 % from its third ticket counter, and for dense filters the
     // crossover moved down with it -- level at 41 kept taps, overlap-save ahead by 0.6 % at 45 and 1.2-2 % at 49,
     // complex and real: profiles/r03_mfma_vs_fft.txt.  Every-other-tap designs stay level up to 49 kept taps.)
+    // Real samples: the matrix-core kernel is ahead of the vector-ALU direct form at EVERY tap count -- 2..16 kept taps, dense or
+    // every other tap: 0.772-0.785 of HBM peak against 0.72-0.737 (profiles/r03_direct_vs_mfma.txt; the direct form's 4-byte
+    // accesses hold it back, the matrix-core kernel stages whole rows through the LDS).  Complex samples: the direct form stays
+    // ahead up to 16 kept taps (0.754-0.759 against 0.735-0.741).
+    const size_t mfma_first = sample_kind == SDR_REAL ? 1 : 17;
     const size_t mfma_last = stride == 2 ? 49 : 44;
-    const bool mfma_auto = (path == SDR_PATH_AUTO || path == SDR_PATH_DIRECT_FORMS) && mfma_smax != 0 && plan.kept >= 17 && plan.kept <= mfma_last;
+    const bool mfma_auto = (path == SDR_PATH_AUTO || path == SDR_PATH_DIRECT_FORMS) && mfma_smax != 0 && plan.kept >= mfma_first && plan.kept <= mfma_last;
     if (mfma_auto) f->use_fft = use_fft = false;
     const bool use_mfma = mfma_auto || (!use_fft && path == SDR_PATH_MFMA);
     if (use_mfma && mfma_smax == 0) {

@@ -236,12 +236,13 @@ def test_16384_point_tiles_on_the_complex_pair_view(ntaps):
 
 def test_kernel_family_chosen_by_measured_crossover():
     """sdr_fir_create picks the family by the measured three-way crossover
-    (profiles/r02_direct_vs_fft_vs_mfma.txt): direct form up to 16 kept taps, the matrix-core
-    kernel for 17..44 kept taps (every-other-tap designs: ..49; profiles/r03_mfma_vs_fft.txt), overlap-save beyond
-    (and for odd-phase Hilbert designs)."""
+    (profiles/r02_direct_vs_fft_vs_mfma.txt): direct form up to 16 kept taps on complex samples, the matrix-core
+    kernel for 17..44 kept taps (every-other-tap designs: ..49; profiles/r03_mfma_vs_fft.txt) and from the first tap
+    on real samples (profiles/r03_direct_vs_mfma.txt), overlap-save beyond (and for odd-phase Hilbert designs)."""
     def name(kind, ntaps, cplx):
         return sdr_amd.FirState(taps_for(kind, ntaps), cplx).kernel_name
-    assert "fir_direct" in name("lowpass", 15, True)
+    assert "fir_direct" in name("lowpass", 15, True) and "fir_direct" in name("hilbert", 31, True)
+    assert "fir_mfma" in name("lowpass", 15, False) and "fir_mfma" in name("hilbert", 31, False) and "fir_mfma" in name("random", 2, False)
     assert "fir_mfma" in name("lowpass", 31, True) and "fir_mfma" in name("lowpass", 44, False)
     assert "fir_fft4096" in name("lowpass", 45, True) and "fir_fft4096" in name("lowpass", 49, False)
     assert "fir_mfma" in name("hilbert", 63, False) and "fir_mfma" in name("hilbert", 95, True)
