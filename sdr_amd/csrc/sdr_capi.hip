@@ -175,6 +175,10 @@ int sdr_amd::plan_direct(const float* taps, size_t ntaps, int sample_kind, Direc
     int nchunks = (int)((span + R - 1) / R);
     nchunks += nchunks & 1;
     if (nchunks < 2) nchunks = 2;
+    // complex samples, four outputs per lane: at least four chunks -- the tile's halo is then 16 samples = one 128-byte line,
+    // where the 64-byte halo of two chunks leaves every tile's first line half used (2..8 taps: 0.733 -> 0.757 of HBM peak,
+    // profiles/r03_direct_vs_mfma.txt; the extra taps are zeros)
+    if (sample_kind == SDR_COMPLEX && R == 4 && nchunks < 4) nchunks = 4;
     p->k = k;
     p->stride = stride;
     p->shift = shift;
