@@ -68,6 +68,8 @@ WORKLOADS = {
     "lp15": ("15-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(15, 0.1), 28, 1, "weak"),
     "lp17": ("17-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(17, 0.1), 28, 1, "weak"),
     "lp41": ("41-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(41, 0.1), 28, 1, "weak"),
+    "lp15r": ("15-tap lowpass on 2^28 real samples, in-memory", False, lambda S: S.fir_lowpass(15, 0.1), 28, 1, "weak"),
+    "lp5": ("5-tap lowpass on 2^28 complex samples, in-memory", True, lambda S: S.fir_lowpass(5, 0.1), 28, 1, "weak"),
     "lp31r": ("31-tap lowpass on 2^28 real samples, in-memory", False, lambda S: S.fir_lowpass(31, 0.1), 28, 1, "weak"),
     "lp47r": ("47-tap lowpass on 2^28 real samples, in-memory", False, lambda S: S.fir_lowpass(47, 0.1), 28, 1, "weak"),
     "hilb63": ("hilbert 63 taps on 2^28 real samples, in-memory", False, lambda S: S.hilbert(63), 28, 1, "weak"),

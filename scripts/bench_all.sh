@@ -4,7 +4,7 @@
 set -u
 OUT=$PWD/gpurun_out/bench_all.txt
 : > "$OUT"
-for w in c2 c2real c1big lp255 hilbc c3 c3real c4 c4chain c5 c1 lp15 lp17 lp31 lp41 lp49 lp65 lp31r lp47r lp63r hilb63 hilb95; do
+for w in c2 c2real c1big lp255 hilbc c3 c3real c4 c4chain c5 c1 lp5 lp15 lp15r lp17 lp31 lp41 lp49 lp65 lp31r lp47r lp63r hilb63 hilb95; do
     timeout -k 10 200 python3 bench.py --workload $w --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
