@@ -278,7 +278,9 @@ static int fir_create_impl(sdr_fir_t** out, const float* taps, size_t ntaps, int
     f->hist_len = plan.hist_len;
     f->use_fft = use_fft;
     // matrix-core direct form: dense (or every-other-tap) filters of up to 129 kept taps
-    const int mfma_smax = (shift == 0) ? mfma_steps_for(plan.kept) : 0;
+    // (complex samples: the 12-step variant from the start -- with 8 steps, up to 17 taps, the kernel runs 0.735-0.741 of HBM peak,
+    // with 12, from 18 taps on, 0.752-0.758: profiles/r03_direct_vs_mfma.txt; the extra steps multiply zeros)
+    const int mfma_smax = (shift == 0) ? mfma_steps_for(sample_kind == SDR_COMPLEX && plan.kept < 18 ? 18 : plan.kept) : 0;
     // Measured three-way crossover (profiles/r02_direct_vs_fft_vs_mfma.txt): with 17..49 kept taps
     // (dense, or every other tap of a Hilbert design up to 97 taps) the matrix-core kernel holds
     // 5.4-6.0 TB/s (0.67-0.75 of HBM peak) where the direct form has turned VALU-bound and the
