@@ -84,7 +84,7 @@ int sdr_fir_create(sdr_fir_t** out, const float* taps, size_t ntaps, int sample_
  * form (reference libs/kfr/dsp/fir.hpp:129-146: one dot product per output), so each output is
  * rounded relative to itself and a NaN / Inf input sample reaches the next `ntaps` outputs and no
  * other.  SDR_NUMERICS_FAST (what sdr_fir_create uses) picks the quickest kernel family per
- * filter; from 33..88 taps up that is overlap-save, whose rounding error is relative to a 4096-
+ * filter; from 45 dense taps (99 of an every-other-tap design) up that is overlap-save, whose rounding error is relative to a 4096-
  * or 16384-point tile (~3e-7 of the TILE's RMS: weak stretches next to strong ones see the strong
  * ones' noise floor) and which loses the whole tile a non-finite sample sits in.
  * SDR_NUMERICS_PER_OUTPUT keeps the handle on the direct-form kernels (VALU or fp32 matrix
